@@ -1,0 +1,149 @@
+/*
+ * mgcmt_hip.h — C-ABI of libmgcmt_hip.so: the MI355X (gfx950) multigrid V-cycle hot path of
+ * AndyMN/MultigridCMT behind plain pointers and sizes.
+ *
+ * The reference is pure Python (no FFI of its own); the boundary it offers is the class API of
+ * MGCMTSolver / MGCMTStencilMaker / MGCMTProcessor.  Each entry point below names the reference
+ * function(s) it replaces (paths relative to the reference root).  The Python classes in
+ * multigridcmt_amd/ bind these with ctypes (see INTEGRATION.md for the binding a maintainer of
+ * the reference would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative mgcmt_status otherwise; the message of the
+ *     last failure on the calling thread is mgcmt_last_error().  No C++ exception crosses the ABI.
+ *   - host buffers are C-contiguous IEEE fp64; the library never keeps a host pointer after return.
+ *   - a plan belongs to one GPU and is not thread-safe; all work of a call is enqueued on the
+ *     `stream` argument (a hipStream_t passed as void*, NULL = the default stream).
+ *   - grids: a 2-D level is rows x cols with vector index k = i*cols + j (the reference's
+ *     kronsum/kron ordering, MGCMTStencilMaker.py:23-24,53); a 1-D level is 1 x n.
+ *   - operators are sums of Kronecker products of tridiagonal factors,
+ *         A = sum_m X_m (x) Y_m  - shift * I,
+ *     X_m over rows, Y_m over columns, each factor given as three arrays (lower, diagonal, upper).
+ *     laplacian(n,"1d") is one term (X = [1], Y = tridiag(1,-2,1)/h^2, MGCMTStencilMaker.py:17-21);
+ *     laplacian(n,"2d") = I(x)L + L(x)I is two (MGCMTStencilMaker.py:23-24).  Galerkin coarse
+ *     operators R*A*P (MGCMTSolver.py:318) keep this form with X_m <- R1 X_m P1, Y_m <- R1 Y_m P1,
+ *     which the library computes at plan creation.
+ */
+#ifndef MGCMT_HIP_H
+#define MGCMT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGCMT_ABI_VERSION 1
+#define MGCMT_MAX_TERMS 4
+#define MGCMT_HALO_ROWS 4 /* rows of halo kept above and below every level's vectors */
+
+typedef enum mgcmt_status {
+  MGCMT_OK = 0,
+  MGCMT_ERR_INVALID = -1,   /* bad argument (sizes not powers of two, level out of range, ...) */
+  MGCMT_ERR_HIP = -2,       /* a HIP runtime call failed */
+  MGCMT_ERR_NOMEM = -3,
+  MGCMT_ERR_UNSUPPORTED = -4
+} mgcmt_status;
+
+/* smoother kinds; MGCMTSolver.py:182-246 and the (commented-out) gseidelrb :248-279 */
+typedef enum mgcmt_smoother {
+  MGCMT_WJACOBI = 0,   /* wjacobi  :182-208  v <- v + w D^-1 (f - A v)                              */
+  MGCMT_GS_LEX = 1,    /* gseidel  :210-227  forward lexicographic Gauss-Seidel (index order)        */
+  MGCMT_SOR_LEX = 2,   /* sor      :229-246  incl. its (D-L)^-1 right-hand-side term (:241)          */
+  MGCMT_GS_MC = 3      /* multicolour GS/SOR: 1-D odd/even, 2-D colours (i%2,j%2) in the order
+                          (0,1),(1,0),(0,0),(1,1) = red-black on a 5-point operator                 */
+} mgcmt_smoother;
+
+/* vector slots of a level */
+typedef enum mgcmt_slot { MGCMT_SLOT_V = 0, MGCMT_SLOT_F = 1, MGCMT_SLOT_T = 2, MGCMT_SLOT_W = 3 } mgcmt_slot;
+
+/* which operator of the plan: A, or the mass operator M of rqmin (MGCMTSolver.py:17-57) */
+typedef enum mgcmt_opsel { MGCMT_OP_A = 0, MGCMT_OP_M = 1 } mgcmt_opsel;
+
+typedef struct mgcmt_plan mgcmt_plan;
+
+typedef struct mgcmt_plan_desc {
+  int32_t dim;          /* 1 or 2 */
+  int32_t nterms;       /* Kronecker terms of A (1-D: 1) */
+  int64_t g;            /* fine grid size per direction (power of two) */
+  int64_t lowest;       /* grid size at which the direct solve happens (vcycle's lowest_level) */
+  const double* xfac;   /* [nterms][3][g] row factors (lower, diag, upper); NULL for dim == 1 */
+  const double* yfac;   /* [nterms][3][g] column factors */
+  int32_t m_nterms;     /* Kronecker terms of the mass operator M, 0 = none */
+  const double* m_xfac; /* as xfac, for M */
+  const double* m_yfac;
+  int32_t nvec;         /* number of simultaneous vectors (columns of vcycle_matrix), >= 1 */
+  int32_t device;       /* HIP device ordinal */
+  int64_t row_begin;    /* rows [row_begin,row_end) of the fine level owned by this plan ...        */
+  int64_t row_end;      /* ... (0,g) on one GPU; multiples of 2^(strip_levels-1) when sharded       */
+  int32_t strip_levels; /* how many of the finest levels are row strips; the rest are whole grids   */
+  int32_t reserved;
+} mgcmt_plan_desc;
+
+const char* mgcmt_last_error(void);
+int mgcmt_abi_version(void);
+int mgcmt_device_count(int* count);
+int mgcmt_device_name(int device, char* buf, int buflen);
+
+/* hierarchy: levels, Galerkin factors (R*A*P, MGCMTSolver.py:318), vector storage */
+int mgcmt_plan_create(const mgcmt_plan_desc* desc, mgcmt_plan** out);
+int mgcmt_plan_destroy(mgcmt_plan* plan);
+int mgcmt_plan_num_levels(const mgcmt_plan* plan, int* levels);
+int mgcmt_plan_level_shape(const mgcmt_plan* plan, int level, int64_t* rows, int64_t* cols, int64_t* row_begin);
+/* host copy of a level's factors, [nterms][3][n] with n = global rows (which=0) or cols (which=1) */
+int mgcmt_plan_get_factors(const mgcmt_plan* plan, int op, int level, int which, double* out, int64_t capacity);
+/* device address of the interior (row 0, col 0) of vector `vec` in `slot` of `level`; rows
+ * -MGCMT_HALO_ROWS..-1 and rows..rows+MGCMT_HALO_ROWS-1 are addressable halo rows */
+int mgcmt_vec_ptr(const mgcmt_plan* plan, int level, int slot, int vec, void** device_ptr);
+
+/* shift(s) mu of (A - mu I): vcycle's shift= (MGCMTSolver.py:287-288), vcycle_matrix's shifts= (:385-388) */
+int mgcmt_set_shifts(mgcmt_plan* plan, const double* shifts, int k, void* stream);
+
+int mgcmt_upload(mgcmt_plan* plan, int level, int slot, int vec, const double* host, int64_t count, void* stream);
+int mgcmt_download(mgcmt_plan* plan, int level, int slot, int vec, double* host, int64_t count, void* stream);
+int mgcmt_fill(mgcmt_plan* plan, int level, int slot, int vec, double value, void* stream);
+int mgcmt_copy(mgcmt_plan* plan, int level, int src_slot, int src_vec, int dst_slot, int dst_vec, void* stream);
+int mgcmt_sync(void* stream);
+
+/* smoothers on V,F of `level` for vectors 0..k-1 (MGCMTSolver.py:182-246) */
+int mgcmt_smooth(mgcmt_plan* plan, int level, int kind, int nu, double omega, int k, void* stream);
+/* F[level+1] <- R (F - (A - mu I) V), V[level+1] <- 0   (MGCMTSolver.py:315-316) */
+int mgcmt_residual_restrict(mgcmt_plan* plan, int level, int k, void* stream);
+/* V[level] <- V[level] + P V[level+1]                    (MGCMTSolver.py:323-324) */
+int mgcmt_prolong_correct(mgcmt_plan* plan, int level, int k, void* stream);
+/* V[last] <- (A_last - mu I)^-1 F[last]                  (spsolve, MGCMTSolver.py:305-308) */
+int mgcmt_coarse_solve(mgcmt_plan* plan, int level, int k, void* stream);
+/* one V-cycle from `level` down: vcycle (:281-329) for k == 1, vcycle_matrix (:375-436, incl. the
+ * Gram-Schmidt at every non-coarsest level, :434) when gram_schmidt != 0.  nu_coarse is the sweep
+ * count on the levels below `level` (the reference does not forward nu1/nu2, so 4: :320,:426). */
+int mgcmt_vcycle(mgcmt_plan* plan, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k,
+                 int gram_schmidt, void* stream);
+/* twogrid (:331-371): exact solve of (R A P - mu I) on level+1 */
+int mgcmt_twogrid(mgcmt_plan* plan, int level, int nu1, int nu2, int kind, double omega, int k, void* stream);
+
+/* dst <- (Op - with_shift*mu I) src        (sparse `*` / .dot, e.g. MGCMTSolver.py:19,315) */
+int mgcmt_apply(mgcmt_plan* plan, int op, int level, int src_slot, int src_vec, int dst_slot, int dst_vec,
+                int with_shift, void* stream);
+/* coarse <- R fine  /  fine <- P coarse    (restriction_matrix * k, MGCMTSolver.py:113,116) */
+int mgcmt_restrict(mgcmt_plan* plan, int level, int src_slot, int src_vec, int dst_slot, int dst_vec, void* stream);
+int mgcmt_prolong(mgcmt_plan* plan, int level, int src_slot, int src_vec, int dst_slot, int dst_vec, int accumulate,
+                  void* stream);
+
+/* vector algebra (MGCMTProcessor.py:10-73; np.dot / np.linalg.norm call sites of MGCMTSolver.py) */
+int mgcmt_dot(mgcmt_plan* plan, int level, int slot_a, int vec_a, int slot_b, int vec_b, double* host_out, void* stream);
+int mgcmt_axpy(mgcmt_plan* plan, int level, double alpha, int x_slot, int x_vec, int y_slot, int y_vec, void* stream);
+int mgcmt_scale(mgcmt_plan* plan, int level, double alpha, int slot, int vec, void* stream);
+/* in-place Gram-Schmidt of vectors 0..k-1 of `slot`: modified != 0 -> MGS (:44-50), else CGS (:34-42) */
+int mgcmt_gramschmidt(mgcmt_plan* plan, int level, int slot, int k, int modified, void* stream);
+/* columns scaled to unit 2-norm (normalize, :52-63) */
+int mgcmt_normalize(mgcmt_plan* plan, int level, int slot, int k, void* stream);
+
+/* timing of the dominant kernel for bench.py: runs `reps` fine-level smoother sweeps between two
+ * HIP events on `stream` and returns the elapsed milliseconds */
+int mgcmt_time_smoother(mgcmt_plan* plan, int level, int kind, int nu, double omega, int reps, double* ms_out,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGCMT_HIP_H */

@@ -1,0 +1,134 @@
+"""ctypes binding of libmgcmt_hip.so (the C-ABI declared in include/mgcmt_hip.h).
+
+The product path has exactly one implementation: the HIP library built for gfx950.  If it is not
+there, or it cannot see a GPU, every compute entry point raises — there is no CPU fallback.
+(``use_library`` exists so the test-suite can point the binding at the host-only emulation build of
+the SAME kernel sources, tests/hip_cpu_mock; nothing in this package calls it.)
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, "libmgcmt_hip.so")
+
+WJACOBI, GS_LEX, SOR_LEX, GS_MC = 0, 1, 2, 3
+SLOT_V, SLOT_F, SLOT_T, SLOT_W = 0, 1, 2, 3
+OP_A, OP_M = 0, 1
+HALO_ROWS = 4
+MAX_TERMS = 4
+MAX_VEC = 32
+ABI_VERSION = 1
+
+
+class MgcmtError(RuntimeError):
+    pass
+
+
+class PlanDesc(ctypes.Structure):
+    _fields_ = [
+        ("dim", c_int32), ("nterms", c_int32), ("g", c_int64), ("lowest", c_int64),
+        ("xfac", POINTER(c_double)), ("yfac", POINTER(c_double)),
+        ("m_nterms", c_int32), ("m_xfac", POINTER(c_double)), ("m_yfac", POINTER(c_double)),
+        ("nvec", c_int32), ("device", c_int32), ("row_begin", c_int64), ("row_end", c_int64),
+        ("strip_levels", c_int32), ("reserved", c_int32),
+    ]
+
+
+_dp = POINTER(c_double)
+_SIGNATURES = {
+    "mgcmt_last_error": (c_char_p, []),
+    "mgcmt_abi_version": (c_int, []),
+    "mgcmt_device_count": (c_int, [POINTER(c_int)]),
+    "mgcmt_device_name": (c_int, [c_int, ctypes.c_char_p, c_int]),
+    "mgcmt_plan_create": (c_int, [POINTER(PlanDesc), POINTER(c_void_p)]),
+    "mgcmt_plan_destroy": (c_int, [c_void_p]),
+    "mgcmt_plan_num_levels": (c_int, [c_void_p, POINTER(c_int)]),
+    "mgcmt_plan_level_shape": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "mgcmt_plan_get_factors": (c_int, [c_void_p, c_int, c_int, c_int, _dp, c_int64]),
+    "mgcmt_vec_ptr": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "mgcmt_set_shifts": (c_int, [c_void_p, _dp, c_int, c_void_p]),
+    "mgcmt_upload": (c_int, [c_void_p, c_int, c_int, c_int, _dp, c_int64, c_void_p]),
+    "mgcmt_download": (c_int, [c_void_p, c_int, c_int, c_int, _dp, c_int64, c_void_p]),
+    "mgcmt_fill": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p]),
+    "mgcmt_copy": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mgcmt_sync": (c_int, [c_void_p]),
+    "mgcmt_smooth": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p]),
+    "mgcmt_residual_restrict": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "mgcmt_prolong_correct": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "mgcmt_coarse_solve": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "mgcmt_vcycle": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p]),
+    "mgcmt_twogrid": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p]),
+    "mgcmt_apply": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mgcmt_restrict": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mgcmt_prolong": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mgcmt_dot": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, _dp, c_void_p]),
+    "mgcmt_axpy": (c_int, [c_void_p, c_int, c_double, c_int, c_int, c_int, c_int, c_void_p]),
+    "mgcmt_scale": (c_int, [c_void_p, c_int, c_double, c_int, c_int, c_void_p]),
+    "mgcmt_gramschmidt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mgcmt_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mgcmt_time_smoother": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, _dp, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+_lib_path = None
+
+
+def _bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mgcmt_abi_version() != ABI_VERSION:
+        raise MgcmtError("ABI version mismatch: library %d, binding %d" % (lib.mgcmt_abi_version(), ABI_VERSION))
+    return lib
+
+
+def use_library(path):
+    """Bind a specific build of the C-ABI (tests only)."""
+    global _lib, _lib_path
+    _lib = _bind(path)
+    _lib_path = path
+    return _lib
+
+
+def library_path():
+    return _lib_path or DEFAULT_LIBRARY
+
+
+def lib():
+    """The bound library; raises MgcmtError when libmgcmt_hip.so has not been built."""
+    global _lib, _lib_path
+    if _lib is None:
+        if not os.path.exists(DEFAULT_LIBRARY):
+            raise MgcmtError(
+                "libmgcmt_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % DEFAULT_LIBRARY)
+        _lib = _bind(DEFAULT_LIBRARY)
+        _lib_path = DEFAULT_LIBRARY
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().mgcmt_last_error()
+        raise MgcmtError("mgcmt error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def device_count():
+    n = c_int(0)
+    check(lib().mgcmt_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_name(device=0):
+    buf = ctypes.create_string_buffer(256)
+    check(lib().mgcmt_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+def as_dp(array):
+    return array.ctypes.data_as(_dp)

@@ -1,0 +1,115 @@
+// Vector algebra of the path: fills, axpy, scaling, batched dot products and the Gram-Schmidt
+// building blocks (MGCMTProcessor.py:10-73; the np.dot / np.linalg.norm call sites of
+// MGCMTSolver.py:19-54).  Reductions are two deterministic passes (per-workgroup partial sums in a
+// fixed order, then one workgroup per result), so results do not depend on scheduling; scalar
+// results stay in device memory and feed the next kernel without a host round trip.
+#include "mgcmt_internal.h"
+
+namespace mgcmt {
+
+namespace {
+
+constexpr int kRedThreads = 256;
+constexpr int kRedMaxBlocks = 1024;
+
+__global__ void k_fill(double* p, long n, double value) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = value;
+}
+
+__global__ void k_axpy(long n, double alpha, const double* __restrict__ x, double* __restrict__ y) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+
+__global__ void k_scale(long n, double alpha, double* __restrict__ x) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= alpha;
+}
+
+// y += (alpha_scale * alpha_dev[0] / (den_dev ? den_dev[0] : 1)) * x
+__global__ void k_axpy_dev(long n, const double* __restrict__ alpha_dev, const double* __restrict__ den_dev, double alpha_scale,
+                           const double* __restrict__ x, double* __restrict__ y) {
+  double a = alpha_scale * alpha_dev[0];
+  if (den_dev) a = a / den_dev[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+
+// x /= sqrt(s[0])   (use_sqrt)  or  x /= s[0]
+__global__ void k_scale_dev(long n, const double* __restrict__ s, int use_sqrt, double* __restrict__ x) {
+  const double d = use_sqrt ? sqrt(s[0]) : s[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = x[i] / d;
+}
+
+__device__ __forceinline__ double block_sum(double v, double* s_buf) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_buf[wave] = v;
+  __syncthreads();
+  double total = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) total += s_buf[w];
+  }
+  __syncthreads();
+  return total;  // valid on thread 0
+}
+
+// partials[q*gridDim.x + b] = sum over block b's slice of x[i]*y_q[i]
+__global__ void __launch_bounds__(kRedThreads) k_dot_partial(long n, const double* __restrict__ x, const double* __restrict__ y, long ystride,
+                                                             double* __restrict__ partials) {
+  __shared__ double s_buf[kRedThreads / 64];
+  const int q = blockIdx.y;
+  const double* yq = y + q * ystride;
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) acc += x[i] * yq[i];
+  const double t = block_sum(acc, s_buf);
+  if (threadIdx.x == 0) partials[(long)q * gridDim.x + blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(kRedThreads) k_dot_final(int nblocks, const double* __restrict__ partials, double* __restrict__ out) {
+  __shared__ double s_buf[kRedThreads / 64];
+  const int q = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) acc += partials[(long)q * nblocks + i];
+  const double t = block_sum(acc, s_buf);
+  if (threadIdx.x == 0) out[q] = t;
+}
+
+inline unsigned blocks_for(long n) {
+  long b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+void launch_fill(hipStream_t s, double* p, long n, double value) { hipLaunchKernelGGL(k_fill, dim3(blocks_for(n)), dim3(256), 0, s, p, n, value); }
+
+void launch_axpy(hipStream_t s, long n, double alpha, const double* x, double* y) {
+  hipLaunchKernelGGL(k_axpy, dim3(blocks_for(n)), dim3(256), 0, s, n, alpha, x, y);
+}
+
+void launch_scale(hipStream_t s, long n, double alpha, double* x) { hipLaunchKernelGGL(k_scale, dim3(blocks_for(n)), dim3(256), 0, s, n, alpha, x); }
+
+void launch_axpy_dev(hipStream_t s, long n, const double* alpha_dev, const double* den_dev, double alpha_scale, const double* x, double* y) {
+  hipLaunchKernelGGL(k_axpy_dev, dim3(blocks_for(n)), dim3(256), 0, s, n, alpha_dev, den_dev, alpha_scale, x, y);
+}
+
+void launch_scale_dev(hipStream_t s, long n, const double* s_dev, int use_sqrt, double* x) {
+  hipLaunchKernelGGL(k_scale_dev, dim3(blocks_for(n)), dim3(256), 0, s, n, s_dev, use_sqrt, x);
+}
+
+int reduce_blocks(long n) {
+  long b = (n + (long)kRedThreads * 8 - 1) / ((long)kRedThreads * 8);
+  if (b > kRedMaxBlocks) b = kRedMaxBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+void launch_dots(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, double* out) {
+  const int nb = reduce_blocks(n);
+  hipLaunchKernelGGL(k_dot_partial, dim3(nb, nq), dim3(kRedThreads), 0, s, n, x, y, ystride, partials);
+  hipLaunchKernelGGL(k_dot_final, dim3(nq), dim3(kRedThreads), 0, s, nb, partials, out);
+}
+
+}  // namespace mgcmt

@@ -1,0 +1,208 @@
+// Baseline (one launch per operation) stencil kernels of the multigrid path, fp64, gfx950.
+//
+// Every level is a rows x cols grid stored row-major (k = i*cols + j) with MGCMT_HALO_ROWS halo
+// rows above and below, so a kernel never branches on the row direction: rows -1 and nr hold
+// either zeros (global Dirichlet boundary, MGCMTStencilMaker.py:17-21) or a neighbour strip's
+// rows.  The column direction is predicated.  The operator is A = sum_m X_m (x) Y_m with
+// tridiagonal factors (see include/mgcmt_hip.h); the shift mu of (A - mu I) is read per vector
+// from `shifts` (MGCMTSolver.py:287-288, :385-388).
+//
+// These kernels are the simple, obviously-correct forms; kernels_fused.hip holds the LDS-staged
+// row-streaming kernels that the V-cycle uses on large levels.
+#include "mgcmt_internal.h"
+
+namespace mgcmt {
+
+namespace {
+
+struct Point {
+  double off;   // sum over the 8 (or 4, or 2) neighbours of a_kj v_j
+  double diag;  // a_kk without the shift
+};
+
+// Neighbour sum and diagonal of the level operator at (i, j) of vector `v`.
+__device__ __forceinline__ Point eval_point(const KOp& op, const double* __restrict__ v, long nc, long i, long j) {
+  const double* c = v + i * nc + j;
+  const bool hw = j > 0, he = j + 1 < nc;
+  Point r;
+  if (op.five_point) {
+    const double w = hw ? c[-1] : 0.0, e = he ? c[1] : 0.0;
+    double acc = op.cw * (w + e);
+    if (op.cn != 0.0) acc += op.cn * (c[-nc] + c[nc]);
+    r.off = acc;
+    r.diag = op.c0;
+    return r;
+  }
+  const double n = c[-nc], s = c[nc];
+  const double w = hw ? c[-1] : 0.0, e = he ? c[1] : 0.0;
+  const double nw = hw ? c[-nc - 1] : 0.0, ne = he ? c[-nc + 1] : 0.0;
+  const double sw = hw ? c[nc - 1] : 0.0, se = he ? c[nc + 1] : 0.0;
+  double off = 0.0, diag = 0.0;
+  for (int m = 0; m < op.nterms; ++m) {
+    const double* X = op.X[m] + i;
+    const double* Y = op.Y[m] + j;
+    const double xl = X[0], xd = X[op.ldx], xu = X[2 * op.ldx];
+    const double yl = Y[0], yd = Y[op.ldy], yu = Y[2 * op.ldy];
+    const double rn = yl * nw + yd * n + yu * ne;
+    const double rc = yl * w + yu * e;
+    const double rs = yl * sw + yd * s + yu * se;
+    off += xl * rn + xd * rc + xu * rs;
+    diag += xd * yd;
+  }
+  r.off = off;
+  r.diag = diag;
+  return r;
+}
+
+// dst = (A - mu I) src
+__global__ void k_apply(KGrid g, KOp op, KVec src, KVec dst, const double* __restrict__ shifts) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = (long)blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.nr || j >= g.nc) return;
+  const int q = blockIdx.z;
+  const double mu = shifts ? shifts[q] : 0.0;
+  const double* v = src.p + q * src.stride;
+  const Point p = eval_point(op, v, g.nc, i, j);
+  dst.p[q * dst.stride + i * g.nc + j] = p.off + (p.diag - mu) * v[i * g.nc + j];
+}
+
+// weighted Jacobi, out of place:  v' = v + w (f - (A - mu I) v) / d     (MGCMTSolver.py:193-206)
+__global__ void k_wjacobi(KGrid g, KOp op, KVec vin, KVec f, KVec vout, const double* __restrict__ shifts, double omega) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = (long)blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.nr || j >= g.nc) return;
+  const int q = blockIdx.z;
+  const double mu = shifts[q];
+  const double* v = vin.p + q * vin.stride;
+  const Point p = eval_point(op, v, g.nc, i, j);
+  const double d = p.diag - mu;
+  const double vc = v[i * g.nc + j];
+  const double res = f.p[q * f.stride + i * g.nc + j] - (p.off + d * vc);
+  vout.p[q * vout.stride + i * g.nc + j] = vc + omega * (res / d);
+}
+
+// one colour (ca, cb) = (i%2, j%2) of the multicolour Gauss-Seidel / SOR sweep, in place
+__global__ void k_mc_colour(KGrid g, KOp op, KVec vv, KVec f, const double* __restrict__ shifts, double omega, int ca, int cb) {
+  const long j = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x) + cb;
+  const long i = 2 * ((long)blockIdx.y * blockDim.y + threadIdx.y) + ca;
+  if (i >= g.nr || j >= g.nc) return;
+  const int q = blockIdx.z;
+  const double mu = shifts[q];
+  double* v = vv.p + q * vv.stride;
+  const Point p = eval_point(op, v, g.nc, i, j);
+  const double d = p.diag - mu;
+  const double vc = v[i * g.nc + j];
+  const double res = f.p[q * f.stride + i * g.nc + j] - (p.off + d * vc);
+  v[i * g.nc + j] = vc + omega * (res / d);
+}
+
+// r = f - (A - mu I) v                                                   (MGCMTSolver.py:315)
+__global__ void k_residual(KGrid g, KOp op, KVec vv, KVec f, KVec r, const double* __restrict__ shifts) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = (long)blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.nr || j >= g.nc) return;
+  const int q = blockIdx.z;
+  const double mu = shifts[q];
+  const double* v = vv.p + q * vv.stride;
+  const Point p = eval_point(op, v, g.nc, i, j);
+  r.p[q * r.stride + i * g.nc + j] = f.p[q * f.stride + i * g.nc + j] - (p.off + (p.diag - mu) * v[i * g.nc + j]);
+}
+
+// full weighting: rows/cols 2I..2I+2 with weights (1/4, 1/2, 1/4)      (MGCMTStencilMaker.py:57-78)
+__global__ void k_restrict(KGrid fine, KGrid coarse, KVec r, KVec rc) {
+  const long J = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long I = (long)blockIdx.y * blockDim.y + threadIdx.y;
+  if (I >= coarse.nr || J >= coarse.nc) return;
+  const int q = blockIdx.z;
+  const double* p = r.p + q * r.stride;
+  const long nc = fine.nc;
+  const long j0 = 2 * J;
+  const bool h2 = j0 + 2 < nc;
+  double out;
+  if (fine.coarsen_rows) {
+    const double* a = p + (2 * I) * nc + j0;
+    const double* b = a + nc;
+    const double* c = b + nc;  // row 2I+2: the halo row when 2I+2 == nr
+    const double ra = 0.25 * a[0] + 0.5 * a[1] + (h2 ? 0.25 * a[2] : 0.0);
+    const double rb = 0.25 * b[0] + 0.5 * b[1] + (h2 ? 0.25 * b[2] : 0.0);
+    const double rcw = 0.25 * c[0] + 0.5 * c[1] + (h2 ? 0.25 * c[2] : 0.0);
+    out = 0.25 * ra + 0.5 * rb + 0.25 * rcw;
+  } else {
+    const double* a = p + I * nc + j0;
+    out = 0.25 * a[0] + 0.5 * a[1] + (h2 ? 0.25 * a[2] : 0.0);
+  }
+  rc.p[q * rc.stride + I * coarse.nc + J] = out;
+}
+
+// linear / bilinear interpolation: odd fine index takes c[(k-1)/2], even takes the mean of
+// c[k/2-1] and c[k/2] (c[-1] = 0)                                        (MGCMTStencilMaker.py:27-54)
+__global__ void k_prolong(KGrid fine, KGrid coarse, KVec e, KVec vv, int accumulate) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = (long)blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= fine.nr || j >= fine.nc) return;
+  const int q = blockIdx.z;
+  const double* c = e.p + q * e.stride;
+  const long cnc = coarse.nc;
+  const long J = j >> 1;
+  const bool jodd = j & 1;
+  double val;
+  if (fine.coarsen_rows) {
+    const long I = i >> 1;
+    const double* r1 = c + I * cnc;
+    const double a1 = jodd ? r1[J] : 0.5 * (r1[J] + (J > 0 ? r1[J - 1] : 0.0));
+    if (i & 1) {
+      val = a1;
+    } else {
+      const double* r0 = r1 - cnc;  // coarse row I-1: the halo row when I == 0
+      const double a0 = jodd ? r0[J] : 0.5 * (r0[J] + (J > 0 ? r0[J - 1] : 0.0));
+      val = 0.5 * (a0 + a1);
+    }
+  } else {
+    const double* r1 = c + i * cnc;
+    val = jodd ? r1[J] : 0.5 * (r1[J] + (J > 0 ? r1[J - 1] : 0.0));
+  }
+  double* dst = vv.p + q * vv.stride + i * fine.nc + j;
+  *dst = accumulate ? *dst + val : val;
+}
+
+inline dim3 grid2d(long nc, long nr, int k, dim3 b) {
+  return dim3((unsigned)((nc + b.x - 1) / b.x), (unsigned)((nr + b.y - 1) / b.y), (unsigned)k);
+}
+
+inline dim3 block_for(long nr) { return nr == 1 ? dim3(256, 1, 1) : dim3(64, 4, 1); }
+
+}  // namespace
+
+void launch_apply(hipStream_t s, KGrid g, KOp op, KVec src, KVec dst, const double* shifts, int k) {
+  const dim3 b = block_for(g.nr);
+  hipLaunchKernelGGL(k_apply, grid2d(g.nc, g.nr, k, b), b, 0, s, g, op, src, dst, shifts);
+}
+
+void launch_wjacobi(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, const double* shifts, double omega, int k) {
+  const dim3 b = block_for(g.nr);
+  hipLaunchKernelGGL(k_wjacobi, grid2d(g.nc, g.nr, k, b), b, 0, s, g, op, vin, f, vout, shifts, omega);
+}
+
+void launch_mc_colour(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double omega, int ca, int cb, int k) {
+  const long rows = (g.nr - ca + 1) / 2, cols = (g.nc - cb + 1) / 2;
+  if (rows <= 0 || cols <= 0) return;
+  const dim3 b = block_for(g.nr);
+  hipLaunchKernelGGL(k_mc_colour, grid2d(cols, rows, k, b), b, 0, s, g, op, v, f, shifts, omega, ca, cb);
+}
+
+void launch_residual(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, KVec r, const double* shifts, int k) {
+  const dim3 b = block_for(g.nr);
+  hipLaunchKernelGGL(k_residual, grid2d(g.nc, g.nr, k, b), b, 0, s, g, op, v, f, r, shifts);
+}
+
+void launch_restrict(hipStream_t s, KGrid fine, KGrid coarse, KVec r, KVec rc, int k) {
+  const dim3 b = block_for(coarse.nr);
+  hipLaunchKernelGGL(k_restrict, grid2d(coarse.nc, coarse.nr, k, b), b, 0, s, fine, coarse, r, rc);
+}
+
+void launch_prolong(hipStream_t s, KGrid fine, KGrid coarse, KVec e, KVec v, int accumulate, int k) {
+  const dim3 b = block_for(fine.nr);
+  hipLaunchKernelGGL(k_prolong, grid2d(fine.nc, fine.nr, k, b), b, 0, s, fine, coarse, e, v, accumulate);
+}
+
+}  // namespace mgcmt

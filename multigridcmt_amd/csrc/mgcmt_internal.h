@@ -1,0 +1,79 @@
+// Internal declarations shared by the kernel files and the plan/driver of libmgcmt_hip.so.
+// Not part of the ABI (the ABI is include/mgcmt_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mgcmt_hip.h"
+
+namespace mgcmt {
+
+constexpr int kHalo = MGCMT_HALO_ROWS;
+constexpr int kMaxTerms = MGCMT_MAX_TERMS;
+constexpr int kMaxVec = 32;  // upper bound on simultaneous vectors of one launch
+
+// Operator of one level as the kernels see it:  A = sum_m X_m (x) Y_m  (shift applied separately).
+// X[m] / Y[m] point at element 0 of the `lower` array; `diag` is at +ldx, `upper` at +2*ldx.
+// Row factors are stored with kHalo entries before element 0 and after element nr-1 (the local
+// strip's halo rows; zero outside the global grid), column factors span the whole row.
+struct KOp {
+  int nterms;
+  int five_point;  // 1: c0/cn/cw below are valid (constant 5-point / 3-point operator)
+  const double* X[kMaxTerms];
+  const double* Y[kMaxTerms];
+  long ldx, ldy;
+  double c0, cn, cw;  // centre, row-neighbour, column-neighbour coefficient (five_point only)
+};
+
+// A batch of vectors on one level: interior pointer of vector 0, elements between vectors.
+struct KVec {
+  double* p;
+  long stride;
+};
+
+struct KGrid {
+  long nr, nc;       // local rows (strip), columns
+  int coarsen_rows;  // 1 for 2-D (rows are coarsened too), 0 for 1-D
+};
+
+// ---- kernel launchers (kernels_*.hip) --------------------------------------------------------
+// All take the number of vectors k (grid z) and a device pointer to the k shifts.
+
+void launch_apply(hipStream_t s, KGrid g, KOp op, KVec src, KVec dst, const double* shifts, int k);
+void launch_wjacobi(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, const double* shifts, double omega, int k);
+void launch_mc_colour(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double omega, int ca, int cb, int k);
+void launch_residual(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, KVec r, const double* shifts, int k);
+void launch_restrict(hipStream_t s, KGrid fine, KGrid coarse, KVec r, KVec rc, int k);
+void launch_prolong(hipStream_t s, KGrid fine, KGrid coarse, KVec e, KVec v, int accumulate, int k);
+// generalised lexicographic sweep (in place):
+//   v_k <- (alpha d_k v_k + beta f_k - wU sum_{j>k} a_kj v_j - wL sum_{j<k} a_kj v_j^new) / d_k
+void launch_lex_sweep(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta,
+                      double wU, double wL, int k);
+
+// vector algebra; scalar results / inputs live in device memory so nothing syncs with the host
+void launch_fill(hipStream_t s, double* p, long n, double value);
+// y += (alpha_scale * alpha_dev[0] / (den_dev ? den_dev[0] : 1)) * x ;  x /= (use_sqrt ? sqrt(s_dev[0]) : s_dev[0])
+void launch_axpy_dev(hipStream_t s, long n, const double* alpha_dev, const double* den_dev, double alpha_scale, const double* x, double* y);
+void launch_scale_dev(hipStream_t s, long n, const double* s_dev, int use_sqrt, double* x);
+void launch_axpy(hipStream_t s, long n, double alpha, const double* x, double* y);
+void launch_scale(hipStream_t s, long n, double alpha, double* x);
+// out[q] = <x, y_q> for q < nq (y_q = y + q*ystride), deterministic two-pass reduction; `partials`
+// holds at least nq * reduce_blocks(n) doubles
+int reduce_blocks(long n);
+void launch_dots(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, double* out);
+
+// banded LU of (A - mu I) on the coarsest level and its solves (one workgroup per vector)
+struct KBand {
+  long n;        // unknowns
+  int kl;        // half bandwidth
+  int width;     // stored entries per row: 3*kl + 1
+  double* ab;    // [k][n][width]
+  int* piv;      // [k][n]
+  long ab_stride, piv_stride;
+};
+void launch_band_assemble(hipStream_t s, KGrid g, KOp op, const double* shifts, KBand b, int k);
+void launch_band_factor(hipStream_t s, KBand b, int k);
+void launch_band_solve(hipStream_t s, KBand b, KVec rhs, KVec x, int k);
+
+}  // namespace mgcmt

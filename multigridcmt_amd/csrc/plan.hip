@@ -1,0 +1,761 @@
+// Plan (level hierarchy, Galerkin factors, vector storage) and the C-ABI of libmgcmt_hip.so.
+// Host code only; every kernel it enqueues is in kernels_*.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "mgcmt_internal.h"
+
+using namespace mgcmt;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define MG_HIP(expr)                                                                                    \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return fail(MGCMT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+  } while (0)
+
+#define MG_TRY(expr)          \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != MGCMT_OK) return rc_; \
+  } while (0)
+
+bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
+
+// tridiagonal factor on the host: lo, di, up concatenated, length 3n
+struct Tri {
+  int64_t n = 0;
+  std::vector<double> a;
+  double lo(int64_t i) const { return a[i]; }
+  double di(int64_t i) const { return a[n + i]; }
+  double up(int64_t i) const { return a[2 * n + i]; }
+  double at(int64_t r, int64_t c) const {
+    if (c == r - 1) return lo(r);
+    if (c == r) return di(r);
+    if (c == r + 1) return up(r);
+    return 0.0;
+  }
+};
+
+// Galerkin product of one factor: R1 * T * P1 with R1 = full weighting (1/4,1/2,1/4 on fine
+// 2I..2I+2) and P1 = 2 R1^T (MGCMTStencilMaker.py:27-78, MGCMTSolver.py:318).  Stays tridiagonal.
+Tri galerkin(const Tri& f) {
+  static const double rw[3] = {0.25, 0.5, 0.25};
+  static const double pw[3] = {0.5, 1.0, 0.5};
+  Tri c;
+  c.n = f.n / 2;
+  c.a.assign(3 * c.n, 0.0);
+  for (int64_t I = 0; I < c.n; ++I) {
+    for (int dJ = -1; dJ <= 1; ++dJ) {
+      const int64_t J = I + dJ;
+      if (J < 0 || J >= c.n) continue;
+      double acc = 0.0;
+      for (int t = 0; t < 3; ++t) {
+        const int64_t a = 2 * I + t;
+        if (a >= f.n) continue;
+        for (int s = -1; s <= 1; ++s) {
+          const int64_t b = a + s;
+          if (b < 0 || b >= f.n) continue;
+          const int64_t o = b - 2 * J;
+          if (o < 0 || o > 2) continue;
+          acc += rw[t] * f.at(a, b) * pw[o];
+        }
+      }
+      c.a[(dJ + 1) * c.n + I] = acc;
+    }
+  }
+  return c;
+}
+
+Tri identity_tri(int64_t n) {
+  Tri t;
+  t.n = n;
+  t.a.assign(3 * n, 0.0);
+  for (int64_t i = 0; i < n; ++i) t.a[n + i] = 1.0;
+  return t;
+}
+
+struct HostOp {
+  int nterms = 0;
+  std::vector<Tri> X, Y;  // per term
+};
+
+struct DevOp {
+  KOp k{};
+  std::vector<double*> owned;
+};
+
+struct BandState {
+  KBand b{};
+  bool valid = false;
+  int k = 0;
+  std::vector<double> shifts;
+};
+
+struct Level {
+  int64_t gr = 1, gc = 1;  // global rows / cols
+  int64_t r0 = 0, nr = 1;  // local strip
+  int64_t stride = 0;      // elements between vectors (halo rows included)
+  double* base[4] = {nullptr, nullptr, nullptr, nullptr};  // allocation start per slot
+  HostOp hA, hM;
+  DevOp dA, dM;
+  BandState band;
+  KGrid grid() const { return KGrid{(long)nr, (long)gc, 0}; }
+};
+
+}  // namespace
+
+struct mgcmt_plan {
+  int dim = 1;
+  int nvec = 1;
+  int device = 0;
+  int64_t g = 0, lowest = 0;
+  std::vector<Level> levels;
+  double* d_shifts = nullptr;   // [kMaxVec] current shifts
+  double* d_zero = nullptr;     // [kMaxVec] zeros (apply without shift)
+  double* d_partials = nullptr; // reduction scratch
+  double* d_scalars = nullptr;  // [4*kMaxVec] reduction results
+  std::vector<double> h_shifts;
+  bool has_mass = false;
+
+  KGrid kgrid(int l) const {
+    KGrid kg = levels[l].grid();
+    kg.coarsen_rows = dim == 2 ? 1 : 0;
+    return kg;
+  }
+  KVec kvec(int l, int slot, int vec = 0) const {
+    const Level& L = levels[l];
+    return KVec{L.base[slot] + (long)kHalo * L.gc + (long)vec * L.stride, (long)L.stride};
+  }
+  long interior(int l) const { return (long)levels[l].nr * levels[l].gc; }
+};
+
+namespace {
+
+int upload_op(const HostOp& h, const Level& L, int dim, DevOp* d) {
+  KOp& k = d->k;
+  k = KOp{};
+  k.nterms = h.nterms;
+  k.ldx = L.nr + 2 * kHalo;
+  k.ldy = L.gc;
+  for (int m = 0; m < h.nterms; ++m) {
+    std::vector<double> xs(3 * k.ldx, 0.0);
+    for (int part = 0; part < 3; ++part)
+      for (int64_t i = -kHalo; i < L.nr + kHalo; ++i) {
+        const int64_t gi = L.r0 + i;
+        if (gi >= 0 && gi < L.gr) xs[part * k.ldx + (i + kHalo)] = h.X[m].a[part * L.gr + gi];
+      }
+    double *dx = nullptr, *dy = nullptr;
+    MG_HIP(hipMalloc((void**)&dx, xs.size() * sizeof(double)));
+    d->owned.push_back(dx);
+    MG_HIP(hipMemcpy(dx, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
+    MG_HIP(hipMalloc((void**)&dy, 3 * L.gc * sizeof(double)));
+    d->owned.push_back(dy);
+    MG_HIP(hipMemcpy(dy, h.Y[m].a.data(), 3 * L.gc * sizeof(double), hipMemcpyHostToDevice));
+    k.X[m] = dx + kHalo;
+    k.Y[m] = dy;
+  }
+  // constant-coefficient 5-point (2-D) / 3-point (1-D) detection: every factor Toeplitz and the
+  // corner coefficients zero -> the kernels take three scalars instead of the factor arrays
+  auto toeplitz = [](const Tri& t, double* lo, double* di, double* up) {
+    *di = t.di(0);
+    *lo = t.n > 1 ? t.lo(1) : 0.0;
+    *up = t.n > 1 ? t.up(0) : 0.0;
+    for (int64_t i = 0; i < t.n; ++i) {
+      if (t.di(i) != *di) return false;
+      if (i > 0 && t.lo(i) != *lo) return false;
+      if (i + 1 < t.n && t.up(i) != *up) return false;
+    }
+    return true;
+  };
+  double c[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  bool all = h.nterms > 0;
+  for (int m = 0; m < h.nterms && all; ++m) {
+    double x[3], y[3];
+    if (!toeplitz(h.X[m], &x[0], &x[1], &x[2]) || !toeplitz(h.Y[m], &y[0], &y[1], &y[2])) {
+      all = false;
+      break;
+    }
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) c[a][b] += x[a] * y[b];
+  }
+  if (all && c[0][0] == 0 && c[0][2] == 0 && c[2][0] == 0 && c[2][2] == 0 && c[0][1] == c[2][1] && c[1][0] == c[1][2] &&
+      (dim == 2 || c[0][1] == 0)) {
+    k.five_point = 1;
+    k.c0 = c[1][1];
+    k.cn = c[0][1];
+    k.cw = c[1][0];
+  }
+  return MGCMT_OK;
+}
+
+int ensure_slot(mgcmt_plan* p, int l, int slot) {
+  Level& L = p->levels[l];
+  if (L.base[slot]) return MGCMT_OK;
+  const size_t bytes = (size_t)L.stride * p->nvec * sizeof(double);
+  hipError_t e = hipMalloc((void**)&L.base[slot], bytes);
+  if (e != hipSuccess) return fail(MGCMT_ERR_NOMEM, std::string("hipMalloc of a level vector failed: ") + hipGetErrorString(e));
+  MG_HIP(hipMemset(L.base[slot], 0, bytes));
+  return MGCMT_OK;
+}
+
+int check_level(const mgcmt_plan* p, int l) {
+  if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
+  if (l < 0 || l >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "level out of range");
+  return MGCMT_OK;
+}
+
+int check_vec(const mgcmt_plan* p, int l, int slot, int vec) {
+  MG_TRY(check_level(p, l));
+  if (slot < 0 || slot > 3) return fail(MGCMT_ERR_INVALID, "slot out of range");
+  if (vec < 0 || vec >= p->nvec) return fail(MGCMT_ERR_INVALID, "vector index out of range");
+  return MGCMT_OK;
+}
+
+int check_k(const mgcmt_plan* p, int k) {
+  if (k < 1 || k > p->nvec) return fail(MGCMT_ERR_INVALID, "k must be in 1..nvec");
+  return MGCMT_OK;
+}
+
+hipStream_t S(void* s) { return (hipStream_t)s; }
+
+int post_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MGCMT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return MGCMT_OK;
+}
+
+// ---- smoothers --------------------------------------------------------------------------------
+
+int smooth_impl(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hipStream_t s) {
+  Level& L = p->levels[l];
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
+  const KGrid g = p->kgrid(l);
+  const KOp& op = L.dA.k;
+  switch (kind) {
+    case MGCMT_WJACOBI: {
+      MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
+      for (int it = 0; it < nu; ++it) {
+        launch_wjacobi(s, g, op, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_T), p->d_shifts, omega, k);
+        std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
+      }
+      break;
+    }
+    case MGCMT_GS_MC: {
+      static const int order[4][2] = {{0, 1}, {1, 0}, {0, 0}, {1, 1}};
+      for (int it = 0; it < nu; ++it)
+        for (int c = 0; c < 4; ++c)
+          launch_mc_colour(s, g, op, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, omega, order[c][0], order[c][1], k);
+      break;
+    }
+    case MGCMT_GS_LEX:
+    case MGCMT_SOR_LEX: {
+      if (kind == MGCMT_GS_LEX || omega == 1.0) {
+        for (int it = 0; it < nu; ++it)
+          launch_lex_sweep(s, g, op, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, 0.0, 1.0, 1.0, 1.0, k);
+      } else {
+        // reference SOR (MGCMTSolver.py:229-246): v <- (D-wL)^-1((1-w)D + wU) v + w (D-L)^-1 f.
+        // T <- (D-L)^-1 f once, then per sweep the homogeneous recurrence followed by v += w T.
+        MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
+        for (int q = 0; q < k; ++q) launch_fill(s, p->kvec(l, MGCMT_SLOT_T, q).p, p->interior(l), 0.0);
+        launch_lex_sweep(s, g, op, p->kvec(l, MGCMT_SLOT_T), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, 0.0, 1.0, 0.0, 1.0, k);
+        for (int it = 0; it < nu; ++it) {
+          launch_lex_sweep(s, g, op, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, 1.0 - omega, 0.0, omega, omega, k);
+          for (int q = 0; q < k; ++q) launch_axpy(s, p->interior(l), omega, p->kvec(l, MGCMT_SLOT_T, q).p, p->kvec(l, MGCMT_SLOT_V, q).p);
+        }
+      }
+      break;
+    }
+    default:
+      return fail(MGCMT_ERR_INVALID, "unknown smoother kind");
+  }
+  return post_launch();
+}
+
+int residual_restrict_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
+  if (l + 1 >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "no coarser level");
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
+  MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_F));
+  launch_residual(s, p->kgrid(l), p->levels[l].dA.k, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_T), p->d_shifts, k);
+  launch_restrict(s, p->kgrid(l), p->kgrid(l + 1), p->kvec(l, MGCMT_SLOT_T), p->kvec(l + 1, MGCMT_SLOT_F), k);
+  for (int q = 0; q < k; ++q) launch_fill(s, p->kvec(l + 1, MGCMT_SLOT_V, q).p, p->interior(l + 1), 0.0);
+  return post_launch();
+}
+
+int prolong_correct_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
+  if (l + 1 >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "no coarser level");
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
+  launch_prolong(s, p->kgrid(l), p->kgrid(l + 1), p->kvec(l + 1, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_V), 1, k);
+  return post_launch();
+}
+
+int coarse_solve_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
+  Level& L = p->levels[l];
+  if (L.nr != L.gr) return fail(MGCMT_ERR_UNSUPPORTED, "direct solve on a row strip");
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
+  BandState& B = L.band;
+  const long n = (long)L.nr * L.gc;
+  const int kl = L.nr == 1 ? 1 : (int)L.gc + 1;
+  if (kl > 129) return fail(MGCMT_ERR_UNSUPPORTED, "lowest_level too large for the direct solve (2-D: at most 128)");
+  if (!B.b.ab) {
+    B.b.n = n;
+    B.b.kl = kl;
+    B.b.width = 3 * kl + 1;
+    B.b.ab_stride = n * B.b.width;
+    B.b.piv_stride = n;
+    MG_HIP(hipMalloc((void**)&B.b.ab, sizeof(double) * B.b.ab_stride * p->nvec));
+    MG_HIP(hipMalloc((void**)&B.b.piv, sizeof(int) * B.b.piv_stride * p->nvec));
+  }
+  bool same = B.valid && B.k >= k;
+  if (same)
+    for (int q = 0; q < k; ++q) same = same && B.shifts[q] == p->h_shifts[q];
+  if (!same) {
+    launch_band_assemble(s, p->kgrid(l), L.dA.k, p->d_shifts, B.b, k);
+    launch_band_factor(s, B.b, k);
+    B.valid = true;
+    B.k = k;
+    B.shifts.assign(p->h_shifts.begin(), p->h_shifts.begin() + k);
+  }
+  launch_band_solve(s, B.b, p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_V), k);
+  return post_launch();
+}
+
+// ---- Gram-Schmidt -------------------------------------------------------------------------------
+
+int gramschmidt_impl(mgcmt_plan* p, int l, int slot, int k, int modified, hipStream_t s) {
+  MG_TRY(ensure_slot(p, l, slot));
+  const long n = p->interior(l);
+  const long stride = p->levels[l].stride;
+  double* a0 = p->kvec(l, slot, 0).p;
+  double* sc = p->d_scalars;
+  if (modified) {
+    // MGCMTProcessor.py:44-50: q_i = a_i/|a_i|; a_j -= (<a_j,q_i>/<q_i,q_i>) q_i for j > i
+    for (int i = 0; i < k; ++i) {
+      double* ai = a0 + i * stride;
+      launch_dots(s, n, ai, ai, 0, 1, p->d_partials, sc);
+      launch_scale_dev(s, n, sc, 1, ai);
+      if (i + 1 < k) {
+        // sc[0] = <q_i,q_i>, sc[1+t] = <q_i, a_{i+1+t}>
+        launch_dots(s, n, ai, ai, stride, k - i, p->d_partials, sc);
+        for (int j = i + 1; j < k; ++j) launch_axpy_dev(s, n, sc + (j - i), sc, -1.0, ai, a0 + j * stride);
+      }
+    }
+  } else {
+    // MGCMTProcessor.py:34-42: u_j = a_j - sum_{i<j} (<a_j,u_i>/<u_i,u_i>) u_i with the ORIGINAL a_j in every
+    // inner product, then all columns normalised
+    for (int j = 1; j < k; ++j) {
+      double* aj = a0 + j * stride;
+      launch_dots(s, n, aj, a0, stride, j, p->d_partials, sc);                  // <a_j, u_i>, i < j
+      for (int i = 0; i < j; ++i) launch_dots(s, n, a0 + i * stride, a0 + i * stride, 0, 1, p->d_partials + kMaxVec * 1024, sc + kMaxVec + i);
+      for (int i = 0; i < j; ++i) launch_axpy_dev(s, n, sc + i, sc + kMaxVec + i, -1.0, a0 + i * stride, aj);
+    }
+    for (int i = 0; i < k; ++i) {
+      double* ai = a0 + i * stride;
+      launch_dots(s, n, ai, ai, 0, 1, p->d_partials, sc);
+      launch_scale_dev(s, n, sc, 1, ai);
+    }
+  }
+  return post_launch();
+}
+
+}  // namespace
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+
+extern "C" {
+
+const char* mgcmt_last_error(void) { return g_last_error.c_str(); }
+
+int mgcmt_abi_version(void) { return MGCMT_ABI_VERSION; }
+
+int mgcmt_device_count(int* count) {
+  if (!count) return fail(MGCMT_ERR_INVALID, "null count");
+  MG_HIP(hipGetDeviceCount(count));
+  return MGCMT_OK;
+}
+
+int mgcmt_device_name(int device, char* buf, int buflen) {
+  if (!buf || buflen <= 0) return fail(MGCMT_ERR_INVALID, "bad buffer");
+  hipDeviceProp_t prop;
+  MG_HIP(hipGetDeviceProperties(&prop, device));
+  snprintf(buf, buflen, "%s (%s)", prop.name, prop.gcnArchName);
+  return MGCMT_OK;
+}
+
+int mgcmt_plan_create(const mgcmt_plan_desc* d, mgcmt_plan** out) {
+  if (!d || !out) return fail(MGCMT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (d->dim != 1 && d->dim != 2) return fail(MGCMT_ERR_INVALID, "dim must be 1 or 2");
+  if (!is_pow2(d->g) || !is_pow2(d->lowest) || d->lowest > d->g) return fail(MGCMT_ERR_INVALID, "g and lowest must be powers of two with lowest <= g");
+  if (d->g < 2) return fail(MGCMT_ERR_INVALID, "Length of start vector is not a power of 2");
+  if (d->lowest < 2) return fail(MGCMT_ERR_INVALID, "lowest must be at least 2");
+  if (d->nterms < 1 || d->nterms > kMaxTerms || d->m_nterms < 0 || d->m_nterms > kMaxTerms) return fail(MGCMT_ERR_INVALID, "nterms out of range");
+  if (!d->yfac || (d->dim == 2 && !d->xfac)) return fail(MGCMT_ERR_INVALID, "missing factor arrays");
+  if (d->nvec < 1 || d->nvec > kMaxVec) return fail(MGCMT_ERR_INVALID, "nvec out of range (1..32)");
+  int64_t rb = d->row_begin, re = d->row_end;
+  if (d->dim == 1 || (rb == 0 && re == 0)) {
+    rb = 0;
+    re = d->dim == 2 ? d->g : 1;
+  }
+  if (d->dim == 2 && (rb < 0 || re > d->g || rb >= re)) return fail(MGCMT_ERR_INVALID, "bad row range");
+  MG_HIP(hipSetDevice(d->device));
+
+  mgcmt_plan* p = new mgcmt_plan();
+  p->dim = d->dim;
+  p->nvec = d->nvec;
+  p->device = d->device;
+  p->g = d->g;
+  p->lowest = d->lowest;
+  p->has_mass = d->m_nterms > 0;
+  p->h_shifts.assign(kMaxVec, 0.0);
+
+  int nlev = 1;
+  for (int64_t s = d->g; s > d->lowest; s >>= 1) ++nlev;
+  const bool whole = (rb == 0 && re == (d->dim == 2 ? d->g : 1));
+  int strip_levels = whole ? 0 : (d->strip_levels > 0 ? d->strip_levels : nlev);
+  if (strip_levels > nlev) strip_levels = nlev;
+  if (!whole) {
+    const int64_t align = (int64_t)1 << (strip_levels - 1);
+    if (rb % align || re % align) {
+      delete p;
+      return fail(MGCMT_ERR_INVALID, "strip bounds must be multiples of 2^(strip_levels-1)");
+    }
+  }
+
+  p->levels.resize(nlev);
+  auto load = [&](const double* src, int m, int64_t n) {
+    Tri t;
+    t.n = n;
+    t.a.assign(src + (size_t)m * 3 * n, src + (size_t)(m + 1) * 3 * n);
+    return t;
+  };
+  for (int l = 0; l < nlev; ++l) {
+    Level& L = p->levels[l];
+    L.gc = d->g >> l;
+    L.gr = d->dim == 2 ? (d->g >> l) : 1;
+    if (l < strip_levels && !whole) {
+      L.r0 = rb >> l;
+      L.nr = (re - rb) >> l;
+    } else {
+      L.r0 = 0;
+      L.nr = L.gr;
+    }
+    L.stride = ((L.nr + 2 * kHalo) * L.gc + 31) / 32 * 32;
+    auto build = [&](HostOp& h, const HostOp* finer, int nterms, const double* xf, const double* yf) {
+      h.nterms = nterms;
+      h.X.resize(nterms);
+      h.Y.resize(nterms);
+      for (int m = 0; m < nterms; ++m) {
+        if (l == 0) {
+          h.Y[m] = load(yf, m, d->g);
+          h.X[m] = d->dim == 2 ? load(xf, m, d->g) : identity_tri(1);
+        } else {
+          h.Y[m] = galerkin(finer->Y[m]);
+          h.X[m] = d->dim == 2 ? galerkin(finer->X[m]) : identity_tri(1);
+        }
+      }
+    };
+    build(L.hA, l ? &p->levels[l - 1].hA : nullptr, d->nterms, d->xfac, d->yfac);
+    if (p->has_mass) build(L.hM, l ? &p->levels[l - 1].hM : nullptr, d->m_nterms, d->m_xfac, d->m_yfac);
+    int rc = upload_op(L.hA, L, d->dim, &L.dA);
+    if (rc == MGCMT_OK && p->has_mass) rc = upload_op(L.hM, L, d->dim, &L.dM);
+    if (rc != MGCMT_OK) {
+      mgcmt_plan_destroy(p);
+      return rc;
+    }
+  }
+  hipError_t e = hipMalloc((void**)&p->d_shifts, sizeof(double) * kMaxVec);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_zero, sizeof(double) * kMaxVec);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_partials, sizeof(double) * (kMaxVec + 1) * 1024 * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_scalars, sizeof(double) * 4 * kMaxVec);
+  if (e == hipSuccess) e = hipMemset(p->d_shifts, 0, sizeof(double) * kMaxVec);
+  if (e == hipSuccess) e = hipMemset(p->d_zero, 0, sizeof(double) * kMaxVec);
+  if (e != hipSuccess) {
+    mgcmt_plan_destroy(p);
+    return fail(MGCMT_ERR_HIP, std::string("plan scratch allocation: ") + hipGetErrorString(e));
+  }
+  *out = p;
+  return MGCMT_OK;
+}
+
+int mgcmt_plan_destroy(mgcmt_plan* p) {
+  if (!p) return MGCMT_OK;
+  for (Level& L : p->levels) {
+    for (int s = 0; s < 4; ++s)
+      if (L.base[s]) (void)hipFree(L.base[s]);
+    for (double* q : L.dA.owned) (void)hipFree(q);
+    for (double* q : L.dM.owned) (void)hipFree(q);
+    if (L.band.b.ab) (void)hipFree(L.band.b.ab);
+    if (L.band.b.piv) (void)hipFree(L.band.b.piv);
+  }
+  if (p->d_shifts) (void)hipFree(p->d_shifts);
+  if (p->d_zero) (void)hipFree(p->d_zero);
+  if (p->d_partials) (void)hipFree(p->d_partials);
+  if (p->d_scalars) (void)hipFree(p->d_scalars);
+  delete p;
+  return MGCMT_OK;
+}
+
+int mgcmt_plan_num_levels(const mgcmt_plan* p, int* levels) {
+  if (!p || !levels) return fail(MGCMT_ERR_INVALID, "null argument");
+  *levels = (int)p->levels.size();
+  return MGCMT_OK;
+}
+
+int mgcmt_plan_level_shape(const mgcmt_plan* p, int l, int64_t* rows, int64_t* cols, int64_t* row_begin) {
+  MG_TRY(check_level(p, l));
+  if (rows) *rows = p->levels[l].nr;
+  if (cols) *cols = p->levels[l].gc;
+  if (row_begin) *row_begin = p->levels[l].r0;
+  return MGCMT_OK;
+}
+
+int mgcmt_plan_get_factors(const mgcmt_plan* p, int op, int l, int which, double* out, int64_t capacity) {
+  MG_TRY(check_level(p, l));
+  const HostOp& h = op == MGCMT_OP_M ? p->levels[l].hM : p->levels[l].hA;
+  if (op == MGCMT_OP_M && !p->has_mass) return fail(MGCMT_ERR_INVALID, "plan has no mass operator");
+  const std::vector<Tri>& f = which == 0 ? h.X : h.Y;
+  int64_t need = 0;
+  for (const Tri& t : f) need += (int64_t)t.a.size();
+  if (!out || capacity < need) return fail(MGCMT_ERR_INVALID, "factor buffer too small");
+  int64_t o = 0;
+  for (const Tri& t : f) {
+    memcpy(out + o, t.a.data(), t.a.size() * sizeof(double));
+    o += (int64_t)t.a.size();
+  }
+  return MGCMT_OK;
+}
+
+int mgcmt_vec_ptr(const mgcmt_plan* p, int l, int slot, int vec, void** device_ptr) {
+  MG_TRY(check_vec(p, l, slot, vec));
+  if (!device_ptr) return fail(MGCMT_ERR_INVALID, "null pointer");
+  MG_TRY(ensure_slot(const_cast<mgcmt_plan*>(p), l, slot));
+  *device_ptr = p->kvec(l, slot, vec).p;
+  return MGCMT_OK;
+}
+
+int mgcmt_set_shifts(mgcmt_plan* p, const double* shifts, int k, void* stream) {
+  if (!p || !shifts) return fail(MGCMT_ERR_INVALID, "null argument");
+  MG_TRY(check_k(p, k));
+  for (int q = 0; q < k; ++q) p->h_shifts[q] = shifts[q];
+  // the host array may be reused immediately by the caller: stage through the plan's own copy
+  MG_HIP(hipMemcpyAsync(p->d_shifts, p->h_shifts.data(), sizeof(double) * k, hipMemcpyHostToDevice, S(stream)));
+  MG_HIP(hipStreamSynchronize(S(stream)));
+  return MGCMT_OK;
+}
+
+int mgcmt_upload(mgcmt_plan* p, int l, int slot, int vec, const double* host, int64_t count, void* stream) {
+  MG_TRY(check_vec(p, l, slot, vec));
+  if (!host || count != p->interior(l)) return fail(MGCMT_ERR_INVALID, "upload: count must equal rows*cols of the level");
+  MG_TRY(ensure_slot(p, l, slot));
+  MG_HIP(hipMemcpyAsync(p->kvec(l, slot, vec).p, host, sizeof(double) * count, hipMemcpyHostToDevice, S(stream)));
+  MG_HIP(hipStreamSynchronize(S(stream)));
+  return MGCMT_OK;
+}
+
+int mgcmt_download(mgcmt_plan* p, int l, int slot, int vec, double* host, int64_t count, void* stream) {
+  MG_TRY(check_vec(p, l, slot, vec));
+  if (!host || count != p->interior(l)) return fail(MGCMT_ERR_INVALID, "download: count must equal rows*cols of the level");
+  MG_TRY(ensure_slot(p, l, slot));
+  MG_HIP(hipMemcpyAsync(host, p->kvec(l, slot, vec).p, sizeof(double) * count, hipMemcpyDeviceToHost, S(stream)));
+  MG_HIP(hipStreamSynchronize(S(stream)));
+  return MGCMT_OK;
+}
+
+int mgcmt_fill(mgcmt_plan* p, int l, int slot, int vec, double value, void* stream) {
+  MG_TRY(check_vec(p, l, slot, vec));
+  MG_TRY(ensure_slot(p, l, slot));
+  launch_fill(S(stream), p->kvec(l, slot, vec).p, p->interior(l), value);
+  return post_launch();
+}
+
+int mgcmt_copy(mgcmt_plan* p, int l, int src_slot, int src_vec, int dst_slot, int dst_vec, void* stream) {
+  MG_TRY(check_vec(p, l, src_slot, src_vec));
+  MG_TRY(check_vec(p, l, dst_slot, dst_vec));
+  MG_TRY(ensure_slot(p, l, src_slot));
+  MG_TRY(ensure_slot(p, l, dst_slot));
+  MG_HIP(hipMemcpyAsync(p->kvec(l, dst_slot, dst_vec).p, p->kvec(l, src_slot, src_vec).p, sizeof(double) * p->interior(l),
+                        hipMemcpyDeviceToDevice, S(stream)));
+  return MGCMT_OK;
+}
+
+int mgcmt_sync(void* stream) {
+  MG_HIP(hipStreamSynchronize(S(stream)));
+  return MGCMT_OK;
+}
+
+int mgcmt_smooth(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, void* stream) {
+  MG_TRY(check_level(p, l));
+  MG_TRY(check_k(p, k));
+  if (nu < 0) return fail(MGCMT_ERR_INVALID, "nu must be >= 0");
+  return smooth_impl(p, l, kind, nu, omega, k, S(stream));
+}
+
+int mgcmt_residual_restrict(mgcmt_plan* p, int l, int k, void* stream) {
+  MG_TRY(check_level(p, l));
+  MG_TRY(check_k(p, k));
+  return residual_restrict_impl(p, l, k, S(stream));
+}
+
+int mgcmt_prolong_correct(mgcmt_plan* p, int l, int k, void* stream) {
+  MG_TRY(check_level(p, l));
+  MG_TRY(check_k(p, k));
+  return prolong_correct_impl(p, l, k, S(stream));
+}
+
+int mgcmt_coarse_solve(mgcmt_plan* p, int l, int k, void* stream) {
+  MG_TRY(check_level(p, l));
+  MG_TRY(check_k(p, k));
+  return coarse_solve_impl(p, l, k, S(stream));
+}
+
+int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k, int gram_schmidt,
+                 void* stream) {
+  MG_TRY(check_level(p, level));
+  MG_TRY(check_k(p, k));
+  const int last = (int)p->levels.size() - 1;
+  hipStream_t s = S(stream);
+  for (int l = level; l < last; ++l) {
+    MG_TRY(smooth_impl(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, s));
+    MG_TRY(residual_restrict_impl(p, l, k, s));
+  }
+  MG_TRY(coarse_solve_impl(p, last, k, s));
+  for (int l = last - 1; l >= level; --l) {
+    MG_TRY(prolong_correct_impl(p, l, k, s));
+    MG_TRY(smooth_impl(p, l, kind, l == level ? nu2 : nu_coarse, omega, k, s));
+    if (gram_schmidt) MG_TRY(gramschmidt_impl(p, l, MGCMT_SLOT_V, k, 1, s));
+  }
+  return MGCMT_OK;
+}
+
+int mgcmt_twogrid(mgcmt_plan* p, int level, int nu1, int nu2, int kind, double omega, int k, void* stream) {
+  MG_TRY(check_level(p, level));
+  MG_TRY(check_k(p, k));
+  if (level + 1 >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "twogrid needs a coarser level");
+  hipStream_t s = S(stream);
+  MG_TRY(smooth_impl(p, level, kind, nu1, omega, k, s));
+  MG_TRY(residual_restrict_impl(p, level, k, s));
+  MG_TRY(coarse_solve_impl(p, level + 1, k, s));
+  MG_TRY(prolong_correct_impl(p, level, k, s));
+  MG_TRY(smooth_impl(p, level, kind, nu2, omega, k, s));
+  return MGCMT_OK;
+}
+
+int mgcmt_apply(mgcmt_plan* p, int op, int l, int src_slot, int src_vec, int dst_slot, int dst_vec, int with_shift, void* stream) {
+  MG_TRY(check_vec(p, l, src_slot, src_vec));
+  MG_TRY(check_vec(p, l, dst_slot, dst_vec));
+  if (src_slot == dst_slot && src_vec == dst_vec) return fail(MGCMT_ERR_INVALID, "apply cannot run in place");
+  if (op == MGCMT_OP_M && !p->has_mass) return fail(MGCMT_ERR_INVALID, "plan has no mass operator");
+  MG_TRY(ensure_slot(p, l, src_slot));
+  MG_TRY(ensure_slot(p, l, dst_slot));
+  const KOp& k = op == MGCMT_OP_M ? p->levels[l].dM.k : p->levels[l].dA.k;
+  const double* sh = with_shift ? p->d_shifts + src_vec : p->d_zero;
+  launch_apply(S(stream), p->kgrid(l), k, p->kvec(l, src_slot, src_vec), p->kvec(l, dst_slot, dst_vec), sh, 1);
+  return post_launch();
+}
+
+int mgcmt_restrict(mgcmt_plan* p, int l, int src_slot, int src_vec, int dst_slot, int dst_vec, void* stream) {
+  MG_TRY(check_vec(p, l, src_slot, src_vec));
+  MG_TRY(check_vec(p, l + 1, dst_slot, dst_vec));
+  MG_TRY(ensure_slot(p, l, src_slot));
+  MG_TRY(ensure_slot(p, l + 1, dst_slot));
+  launch_restrict(S(stream), p->kgrid(l), p->kgrid(l + 1), p->kvec(l, src_slot, src_vec), p->kvec(l + 1, dst_slot, dst_vec), 1);
+  return post_launch();
+}
+
+int mgcmt_prolong(mgcmt_plan* p, int l, int src_slot, int src_vec, int dst_slot, int dst_vec, int accumulate, void* stream) {
+  MG_TRY(check_vec(p, l + 1, src_slot, src_vec));
+  MG_TRY(check_vec(p, l, dst_slot, dst_vec));
+  MG_TRY(ensure_slot(p, l + 1, src_slot));
+  MG_TRY(ensure_slot(p, l, dst_slot));
+  launch_prolong(S(stream), p->kgrid(l), p->kgrid(l + 1), p->kvec(l + 1, src_slot, src_vec), p->kvec(l, dst_slot, dst_vec), accumulate, 1);
+  return post_launch();
+}
+
+int mgcmt_dot(mgcmt_plan* p, int l, int slot_a, int vec_a, int slot_b, int vec_b, double* host_out, void* stream) {
+  MG_TRY(check_vec(p, l, slot_a, vec_a));
+  MG_TRY(check_vec(p, l, slot_b, vec_b));
+  if (!host_out) return fail(MGCMT_ERR_INVALID, "null output");
+  MG_TRY(ensure_slot(p, l, slot_a));
+  MG_TRY(ensure_slot(p, l, slot_b));
+  launch_dots(S(stream), p->interior(l), p->kvec(l, slot_a, vec_a).p, p->kvec(l, slot_b, vec_b).p, 0, 1, p->d_partials, p->d_scalars);
+  MG_TRY(post_launch());
+  MG_HIP(hipMemcpyAsync(host_out, p->d_scalars, sizeof(double), hipMemcpyDeviceToHost, S(stream)));
+  MG_HIP(hipStreamSynchronize(S(stream)));
+  return MGCMT_OK;
+}
+
+int mgcmt_axpy(mgcmt_plan* p, int l, double alpha, int x_slot, int x_vec, int y_slot, int y_vec, void* stream) {
+  MG_TRY(check_vec(p, l, x_slot, x_vec));
+  MG_TRY(check_vec(p, l, y_slot, y_vec));
+  MG_TRY(ensure_slot(p, l, x_slot));
+  MG_TRY(ensure_slot(p, l, y_slot));
+  launch_axpy(S(stream), p->interior(l), alpha, p->kvec(l, x_slot, x_vec).p, p->kvec(l, y_slot, y_vec).p);
+  return post_launch();
+}
+
+int mgcmt_scale(mgcmt_plan* p, int l, double alpha, int slot, int vec, void* stream) {
+  MG_TRY(check_vec(p, l, slot, vec));
+  MG_TRY(ensure_slot(p, l, slot));
+  launch_scale(S(stream), p->interior(l), alpha, p->kvec(l, slot, vec).p);
+  return post_launch();
+}
+
+int mgcmt_gramschmidt(mgcmt_plan* p, int l, int slot, int k, int modified, void* stream) {
+  MG_TRY(check_vec(p, l, slot, 0));
+  MG_TRY(check_k(p, k));
+  return gramschmidt_impl(p, l, slot, k, modified, S(stream));
+}
+
+int mgcmt_normalize(mgcmt_plan* p, int l, int slot, int k, void* stream) {
+  MG_TRY(check_vec(p, l, slot, 0));
+  MG_TRY(check_k(p, k));
+  MG_TRY(ensure_slot(p, l, slot));
+  for (int i = 0; i < k; ++i) {
+    double* a = p->kvec(l, slot, i).p;
+    launch_dots(S(stream), p->interior(l), a, a, 0, 1, p->d_partials, p->d_scalars);
+    launch_scale_dev(S(stream), p->interior(l), p->d_scalars, 1, a);
+  }
+  return post_launch();
+}
+
+int mgcmt_time_smoother(mgcmt_plan* p, int l, int kind, int nu, double omega, int reps, double* ms_out, void* stream) {
+  MG_TRY(check_level(p, l));
+  if (!ms_out || reps < 1) return fail(MGCMT_ERR_INVALID, "bad arguments");
+  hipEvent_t a, b;
+  MG_HIP(hipEventCreate(&a));
+  MG_HIP(hipEventCreate(&b));
+  MG_HIP(hipEventRecord(a, S(stream)));
+  for (int r = 0; r < reps; ++r) MG_TRY(smooth_impl(p, l, kind, nu, omega, 1, S(stream)));
+  MG_HIP(hipEventRecord(b, S(stream)));
+  MG_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  MG_HIP(hipEventElapsedTime(&ms, a, b));
+  *ms_out = (double)ms;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return MGCMT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+"""Structured description of the operators the reference hands to its solver.
+
+The reference passes ``scipy.sparse`` matrices built by ``MGCMTStencilMaker.laplacian``
+(MGCMTStencilMaker.py:15-25), usually pre-scaled — ``(-1 / np.pi ** 2) * laplacian``
+(1DPotMatrixVcycle.py:16, 2DPotMatrixVcycle.py:27) — and sometimes pre-shifted (``A - mu*I`` handed to
+a smoother, MGCMTSolver.py:313).  The kernels are matrix-free: they need the operator as a sum of
+Kronecker products of tridiagonal factors,  A = sum_m X_m (x) Y_m  (rows (x) columns).  This module
+recovers that form from a sparse matrix by an O(nnz) structural check (``recognise``) and offers a
+matrix-free operator object (``StructuredOperator``) for grids too large to assemble.
+"""
+import hashlib
+import math
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def tri(lo, di, up):
+    """Three arrays of length n (lo[0] and up[n-1] ignored -> 0) as one (3, n) float64 block."""
+    t = np.zeros((3, len(di)), dtype=np.float64)
+    t[0, 1:] = np.asarray(lo, dtype=np.float64)[1:] if len(lo) == len(di) else np.asarray(lo, dtype=np.float64)
+    t[1] = di
+    t[2, :-1] = np.asarray(up, dtype=np.float64)[:-1] if len(up) == len(di) else np.asarray(up, dtype=np.float64)
+    return t
+
+
+def tri_identity(n):
+    t = np.zeros((3, n))
+    t[1] = 1.0
+    return t
+
+
+def tri_laplacian(n):
+    """MGCMTStencilMaker.py:17-21 — tridiag(1,-2,1) * (1/h**2), h = 1./n (same float expression)."""
+    h = 1. / n
+    s = 1 / h ** 2
+    t = np.zeros((3, n))
+    t[0, 1:] = 1.0 * s
+    t[1] = -2.0 * s
+    t[2, :-1] = 1.0 * s
+    return t
+
+
+def tri_to_sparse(t):
+    n = t.shape[1]
+    return sp.diags([t[0, 1:], t[1], t[2, :-1]], [-1, 0, 1], shape=(n, n), format="csr")
+
+
+class StructuredOperator:
+    """A = sum_m X_m (x) Y_m on a g x g grid (dimension "2d") or a single tridiagonal (``"1d"``).
+
+    Behaves like the sparse matrix it stands for where the reference's callers need it: scalar
+    ``*`` and ``/``, unary minus, ``.shape``, ``.diagonal()``, ``.tocsr()``/``.toarray()`` (small
+    sizes), and ``A.dot(x)`` / ``A * x`` / ``A @ x`` which run the HIP apply kernel.
+    """
+
+    def __init__(self, dimension, g, terms):
+        self.dimension = dimension
+        self.g = int(g)
+        self.terms = [(None if x is None else np.ascontiguousarray(x, dtype=np.float64),
+                       np.ascontiguousarray(y, dtype=np.float64)) for x, y in terms]
+        n = self.g if dimension == "1d" else self.g * self.g
+        self.shape = (n, n)
+        self._fingerprint = None
+
+    # -- algebra with scalars ---------------------------------------------------------------------
+    def _scaled(self, c):
+        c = float(c)
+        if self.dimension == "1d":
+            return StructuredOperator("1d", self.g, [(None, y * c) for _, y in self.terms])
+        return StructuredOperator("2d", self.g, [(x, y * c) for x, y in self.terms])
+
+    def __mul__(self, other):
+        if np.isscalar(other):
+            return self._scaled(other)
+        return self.dot(other)
+
+    def __rmul__(self, other):
+        if np.isscalar(other):
+            return self._scaled(other)
+        return NotImplemented
+
+    def __truediv__(self, other):
+        return self._scaled(1.0 / other)
+
+    def __neg__(self):
+        return self._scaled(-1.0)
+
+    def __matmul__(self, other):
+        return self.dot(other)
+
+    def shifted(self, mu):
+        """A - mu*I as a structured operator (the shift folded into the first term's diagonal)."""
+        terms = [(None if x is None else x.copy(), y.copy()) for x, y in self.terms]
+        if self.dimension == "1d":
+            terms[0][1][1] -= mu
+        else:
+            terms.append((tri_identity(self.g), tri_identity(self.g) * (-float(mu))))
+        return StructuredOperator(self.dimension, self.g, terms)
+
+    # -- views ----------------------------------------------------------------------------------
+    def diagonal(self):
+        if self.dimension == "1d":
+            return sum(y[1] for _, y in self.terms)
+        return sum(np.outer(x[1], y[1]) for x, y in self.terms).reshape(-1)
+
+    def tocsr(self):
+        if self.shape[0] > (1 << 22):
+            raise MemoryError("refusing to assemble a %d x %d sparse matrix" % self.shape)
+        if self.dimension == "1d":
+            return sum(tri_to_sparse(y) for _, y in self.terms).tocsr()
+        return sum(sp.kron(tri_to_sparse(x), tri_to_sparse(y), format="csr") for x, y in self.terms).tocsr()
+
+    def tocsc(self):
+        return self.tocsr().tocsc()
+
+    def toarray(self):
+        return self.tocsr().toarray()
+
+    def dot(self, x):
+        from .plan import apply_operator
+        return apply_operator(self, x)
+
+    # -- for the plan cache -----------------------------------------------------------------------
+    def factor_blocks(self):
+        """(nterms, xfac or None, yfac) as contiguous [nterms][3][g] arrays for the C-ABI."""
+        yfac = np.ascontiguousarray(np.stack([y for _, y in self.terms]))
+        xfac = None if self.dimension == "1d" else np.ascontiguousarray(np.stack([x for x, _ in self.terms]))
+        return len(self.terms), xfac, yfac
+
+    def fingerprint(self):
+        if self._fingerprint is None:
+            h = hashlib.sha1()
+            h.update(("%s:%d:%d" % (self.dimension, self.g, len(self.terms))).encode())
+            for x, y in self.terms:
+                if x is not None:
+                    h.update(x.tobytes())
+                h.update(y.tobytes())
+            self._fingerprint = h.hexdigest()
+        return self._fingerprint
+
+
+def laplacian_operator(n, dimension="1d"):
+    """Matrix-free counterpart of MGCMTStencilMaker.laplacian (MGCMTStencilMaker.py:15-25)."""
+    n = int(n)
+    if dimension == "1d":
+        return StructuredOperator("1d", n, [(None, tri_laplacian(n))])
+    # kronsum(L, L) = I (x) L + L (x) I   (MGCMTStencilMaker.py:23-24)
+    return StructuredOperator("2d", n, [(tri_identity(n), tri_laplacian(n)), (tri_laplacian(n), tri_identity(n))])
+
+
+class UnrecognisedOperator(ValueError):
+    pass
+
+
+_CACHE = {}
+
+
+def _cache_key(A):
+    return (id(A), A.shape, getattr(A, "nnz", None))
+
+
+def recognise(A, dimension=None):
+    """StructuredOperator for a scipy.sparse matrix of the shapes the reference's callers build.
+
+    1-D: any tridiagonal matrix.  2-D: a 5-point operator  I (x) Y + X (x) I  whose diagonal is
+    separable, d(i,j) = a(i) + b(j) — scaled / shifted Laplacians and separable potentials.  Anything
+    else raises UnrecognisedOperator: the HIP path has no general-sparse kernels and there is no CPU
+    fallback.
+    """
+    if isinstance(A, StructuredOperator):
+        if dimension is not None and A.dimension != dimension:
+            raise UnrecognisedOperator("operator is %s but dimension=%r was requested" % (A.dimension, dimension))
+        return A
+    if not sp.issparse(A):
+        A = sp.csr_matrix(np.asarray(A, dtype=np.float64))
+    key = _cache_key(A)
+    hit = _CACHE.get(key)
+    if hit is not None and hit[0] is A and (dimension is None or hit[1].dimension == dimension):
+        return hit[1]
+    n = A.shape[0]
+    if A.shape[0] != A.shape[1]:
+        raise UnrecognisedOperator("operator must be square")
+    if np.iscomplexobj(A):
+        raise UnrecognisedOperator("complex operators are not supported by the HIP path")
+    M = sp.csr_matrix(A, dtype=np.float64, copy=True)
+    M.eliminate_zeros()
+    nnz = M.nnz
+    op = None
+    if dimension in (None, "1d"):
+        d0, dm, dp = M.diagonal(0), M.diagonal(-1), M.diagonal(1)
+        if np.count_nonzero(d0) + np.count_nonzero(dm) + np.count_nonzero(dp) == nnz:
+            y = np.zeros((3, n))
+            y[0, 1:], y[1], y[2, :-1] = dm, d0, dp
+            op = StructuredOperator("1d", n, [(None, y)])
+    if op is None and dimension in (None, "2d"):
+        g = int(round(math.sqrt(n)))
+        if g * g != n:
+            raise UnrecognisedOperator("2-D operator size %d is not a square number" % n)
+        d0 = M.diagonal(0).reshape(g, g)
+        e = np.zeros(n)
+        e[:-1] = M.diagonal(1)
+        w = np.zeros(n)
+        w[1:] = M.diagonal(-1)
+        s = np.zeros(n)
+        s[:-g] = M.diagonal(g)
+        nn = np.zeros(n)
+        nn[g:] = M.diagonal(-g)
+        counted = sum(np.count_nonzero(a) for a in (d0, e, w, s, nn))
+        e, w, s, nn = e.reshape(g, g), w.reshape(g, g), s.reshape(g, g), nn.reshape(g, g)
+        ok = counted == nnz and not e[:, -1].any() and not w[:, 0].any()
+        ok = ok and np.array_equal(e, np.broadcast_to(e[0], (g, g))) and np.array_equal(w, np.broadcast_to(w[0], (g, g)))
+        ok = ok and np.array_equal(s, np.broadcast_to(s[:, :1], (g, g))) and np.array_equal(nn, np.broadcast_to(nn[:, :1], (g, g)))
+        if ok:
+            c = 0.5 * d0[0, 0]
+            yd = d0[0, :] - c
+            xd = d0[:, 0] - d0[0, 0] + c
+            scale = max(np.abs(d0).max(), 1e-300)
+            ok = np.abs(xd[:, None] + yd[None, :] - d0).max() <= 4 * np.finfo(float).eps * scale
+        if not ok:
+            raise UnrecognisedOperator(
+                "2-D operator is not of the form I (x) Y + X (x) I with a separable diagonal; the HIP path "
+                "handles scaled/shifted Laplacians and separable potentials only")
+        Y = np.zeros((3, g))
+        Y[0], Y[1], Y[2] = w[0], yd, e[0]
+        X = np.zeros((3, g))
+        X[0], X[1], X[2] = nn[:, 0], xd, s[:, 0]
+        op = StructuredOperator("2d", g, [(tri_identity(g), Y), (X, tri_identity(g))])
+    if op is None:
+        raise UnrecognisedOperator("operator is not tridiagonal (1-D)")
+    if len(_CACHE) > 64:
+        _CACHE.clear()
+    _CACHE[key] = (A, op)
+    return op

@@ -1,0 +1,212 @@
+"""Python handle on a device hierarchy (``mgcmt_plan`` of include/mgcmt_hip.h).
+
+One plan = one operator (plus optional mass operator) on one grid size with a fixed coarsest level:
+the Galerkin factors of every level (MGCMTSolver.py:318) and the level vectors live on the GPU.
+"""
+import ctypes
+from collections import OrderedDict
+from ctypes import c_double, c_int, c_int64, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._lib import OP_A, OP_M, SLOT_F, SLOT_T, SLOT_V, SLOT_W, PlanDesc, as_dp, check
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Plan:
+    def __init__(self, op, lowest, nvec=1, mass=None, device=0, row_begin=0, row_end=0, strip_levels=0):
+        self._h = c_void_p()
+        self.op = op
+        self.mass = mass
+        self.dim = 1 if op.dimension == "1d" else 2
+        self.g = op.g
+        self.lowest = int(lowest)
+        self.nvec = int(nvec)
+        self.device = device
+        nterms, xfac, yfac = op.factor_blocks()
+        desc = PlanDesc()
+        desc.dim, desc.nterms, desc.g, desc.lowest = self.dim, nterms, self.g, self.lowest
+        desc.xfac = as_dp(xfac) if xfac is not None else None
+        desc.yfac = as_dp(yfac)
+        keep = [xfac, yfac]
+        if mass is not None:
+            mt, mx, my = mass.factor_blocks()
+            desc.m_nterms = mt
+            desc.m_xfac = as_dp(mx) if mx is not None else None
+            desc.m_yfac = as_dp(my)
+            keep += [mx, my]
+        desc.nvec, desc.device = self.nvec, device
+        desc.row_begin, desc.row_end, desc.strip_levels = row_begin, row_end, strip_levels
+        check(_lib.lib().mgcmt_plan_create(ctypes.byref(desc), ctypes.byref(self._h)))
+        del keep
+        n = c_int(0)
+        check(_lib.lib().mgcmt_plan_num_levels(self._h, ctypes.byref(n)))
+        self.num_levels = n.value
+        self.shapes = [self.level_shape(l) for l in range(self.num_levels)]
+        self._shifts = None
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            _lib.lib().mgcmt_plan_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- geometry ---------------------------------------------------------------------------------
+    def level_shape(self, level):
+        r, c, b = c_int64(0), c_int64(0), c_int64(0)
+        check(_lib.lib().mgcmt_plan_level_shape(self._h, level, ctypes.byref(r), ctypes.byref(c), ctypes.byref(b)))
+        return r.value, c.value, b.value
+
+    def size(self, level=0):
+        r, c, _ = self.shapes[level]
+        return r * c
+
+    def factors(self, level, which, op=OP_A):
+        """Host copy of a level's Kronecker factors: array [nterms, 3, n]."""
+        src = self.op if op == OP_A else self.mass
+        nterms = len(src.terms)
+        n = (self.g >> level) if (which == 1 or self.dim == 2) else 1
+        out = np.zeros((nterms, 3, n))
+        check(_lib.lib().mgcmt_plan_get_factors(self._h, op, level, which, as_dp(out), out.size))
+        return out
+
+    def vec_ptr(self, level, slot, vec=0):
+        p = c_void_p()
+        check(_lib.lib().mgcmt_vec_ptr(self._h, level, slot, vec, ctypes.byref(p)))
+        return p.value
+
+    # -- data -------------------------------------------------------------------------------------
+    def set_shifts(self, shifts, stream=None):
+        s = _f64(np.atleast_1d(shifts)).reshape(-1)
+        check(_lib.lib().mgcmt_set_shifts(self._h, as_dp(s), len(s), stream))
+        self._shifts = s.copy()
+
+    def upload(self, level, slot, vec, host, stream=None):
+        a = _f64(host).reshape(-1)
+        check(_lib.lib().mgcmt_upload(self._h, level, slot, vec, as_dp(a), a.size, stream))
+
+    def download(self, level, slot, vec, stream=None):
+        out = np.empty(self.size(level), dtype=np.float64)
+        check(_lib.lib().mgcmt_download(self._h, level, slot, vec, as_dp(out), out.size, stream))
+        return out
+
+    def fill(self, level, slot, vec, value, stream=None):
+        check(_lib.lib().mgcmt_fill(self._h, level, slot, vec, c_double(value), stream))
+
+    def copy(self, level, src_slot, src_vec, dst_slot, dst_vec, stream=None):
+        check(_lib.lib().mgcmt_copy(self._h, level, src_slot, src_vec, dst_slot, dst_vec, stream))
+
+    def sync(self, stream=None):
+        check(_lib.lib().mgcmt_sync(stream))
+
+    # -- the path ---------------------------------------------------------------------------------
+    def smooth(self, level, kind, nu, omega=1.0, k=1, stream=None):
+        check(_lib.lib().mgcmt_smooth(self._h, level, kind, nu, c_double(omega), k, stream))
+
+    def residual_restrict(self, level, k=1, stream=None):
+        check(_lib.lib().mgcmt_residual_restrict(self._h, level, k, stream))
+
+    def prolong_correct(self, level, k=1, stream=None):
+        check(_lib.lib().mgcmt_prolong_correct(self._h, level, k, stream))
+
+    def coarse_solve(self, level, k=1, stream=None):
+        check(_lib.lib().mgcmt_coarse_solve(self._h, level, k, stream))
+
+    def vcycle(self, nu1, nu2, kind, omega=1.0, k=1, nu_coarse=4, gram_schmidt=False, level=0, stream=None):
+        check(_lib.lib().mgcmt_vcycle(self._h, level, nu1, nu2, nu_coarse, kind, c_double(omega), k,
+                                      1 if gram_schmidt else 0, stream))
+
+    def twogrid(self, nu1, nu2, kind, omega=1.0, k=1, level=0, stream=None):
+        check(_lib.lib().mgcmt_twogrid(self._h, level, nu1, nu2, kind, c_double(omega), k, stream))
+
+    def apply(self, level, src, dst, op=OP_A, with_shift=False, stream=None):
+        check(_lib.lib().mgcmt_apply(self._h, op, level, src[0], src[1], dst[0], dst[1], 1 if with_shift else 0, stream))
+
+    def restrict(self, level, src, dst, stream=None):
+        check(_lib.lib().mgcmt_restrict(self._h, level, src[0], src[1], dst[0], dst[1], stream))
+
+    def prolong(self, level, src, dst, accumulate=False, stream=None):
+        check(_lib.lib().mgcmt_prolong(self._h, level, src[0], src[1], dst[0], dst[1], 1 if accumulate else 0, stream))
+
+    def dot(self, level, a, b, stream=None):
+        out = c_double(0.0)
+        check(_lib.lib().mgcmt_dot(self._h, level, a[0], a[1], b[0], b[1], ctypes.byref(out), stream))
+        return out.value
+
+    def axpy(self, level, alpha, x, y, stream=None):
+        check(_lib.lib().mgcmt_axpy(self._h, level, c_double(alpha), x[0], x[1], y[0], y[1], stream))
+
+    def scale(self, level, alpha, v, stream=None):
+        check(_lib.lib().mgcmt_scale(self._h, level, c_double(alpha), v[0], v[1], stream))
+
+    def gramschmidt(self, level, slot, k, modified=1, stream=None):
+        check(_lib.lib().mgcmt_gramschmidt(self._h, level, slot, k, 1 if modified else 0, stream))
+
+    def normalize(self, level, slot, k, stream=None):
+        check(_lib.lib().mgcmt_normalize(self._h, level, slot, k, stream))
+
+    def time_smoother(self, level, kind, nu, omega, reps, stream=None):
+        ms = c_double(0.0)
+        check(_lib.lib().mgcmt_time_smoother(self._h, level, kind, nu, c_double(omega), reps, ctypes.byref(ms), stream))
+        return ms.value
+
+
+# --------------------------------------------------------------------------------------------------
+# plan cache: callers of the reference API pass the operator on every call
+# --------------------------------------------------------------------------------------------------
+
+_PLANS = OrderedDict()
+_MAX_PLANS = 6
+
+
+def _log2(x):
+    return int(x).bit_length() - 1
+
+
+def get_plan(op, lowest, nvec=1, mass=None):
+    """A cached plan for (operator, coarsest size, mass operator) with room for at least nvec vectors."""
+    key = (op.fingerprint(), int(lowest), None if mass is None else mass.fingerprint())
+    plan = _PLANS.get(key)
+    if plan is not None and plan.nvec >= nvec:
+        _PLANS.move_to_end(key)
+        return plan
+    if plan is not None:
+        plan.close()
+        del _PLANS[key]
+    plan = Plan(op, lowest, nvec=nvec, mass=mass)
+    _PLANS[key] = plan
+    while len(_PLANS) > _MAX_PLANS:
+        _, old = _PLANS.popitem(last=False)
+        old.close()
+    return plan
+
+
+def release_plans():
+    """Free every cached device hierarchy."""
+    while _PLANS:
+        _, p = _PLANS.popitem()
+        p.close()
+
+
+def apply_operator(op, x):
+    """A @ x on the GPU for a StructuredOperator (x: (n,), (n,1) or (n,k))."""
+    x = np.asarray(x, dtype=np.float64)
+    n = op.shape[0]
+    cols = x.reshape(n, -1)
+    plan = get_plan(op, op.g, nvec=1)      # a single level is enough
+    out = np.empty_like(cols)
+    for c in range(cols.shape[1]):
+        plan.upload(0, SLOT_V, 0, cols[:, c])
+        plan.apply(0, (SLOT_V, 0), (SLOT_T, 0))
+        out[:, c] = plan.download(0, SLOT_T, 0)
+    return out.reshape(x.shape)

@@ -1,0 +1,385 @@
+"""MGCMTSolver — the reference's solver class (MGCMTSolver.py:8-436) with every numerical step on
+the MI355X through libmgcmt_hip.so.
+
+Signatures (positional order, keyword names, defaults), return shapes and the reference's quirks are
+kept; trailing keyword-only additions are marked "addition".  Operators arrive as ``scipy.sparse``
+matrices exactly as in the reference's drivers and are mapped to the matrix-free representation by
+``operators.recognise``; operators it cannot map raise (there is no CPU fallback).
+"""
+import functools
+import math
+
+import numpy as np
+import scipy.linalg
+
+from . import _lib
+from ._lib import GS_LEX, GS_MC, OP_A, OP_M, SLOT_F, SLOT_T, SLOT_V, SLOT_W, SOR_LEX, WJACOBI
+from .operators import StructuredOperator, laplacian_operator, recognise
+from .plan import get_plan
+from .processor import MGCMTProcessor
+from .stencil_maker import MGCMTStencilMaker
+
+
+def _is_pow2(x):
+    x = int(x)
+    return x > 0 and (x & (x - 1)) == 0
+
+
+def _force_column(a, n):
+    """The reference sets ``.shape = (n, 1)`` on the CALLER's arrays (MGCMTSolver.py:187-191,297-300)."""
+    if isinstance(a, np.ndarray) and a.shape != (n, 1):
+        try:
+            a.shape = (n, 1)
+        except AttributeError:
+            pass
+    return a
+
+
+class MGCMTSolver:
+    """
+    Same constructor as the reference (MGCMTSolver.py:13-15): owns a stencil maker and a processor.
+    """
+
+    def __init__(self):
+        self.stencil_maker = MGCMTStencilMaker()
+        self.processor = MGCMTProcessor()
+
+    # ------------------------------------------------------------------------------------------
+    # smoothers
+    # ------------------------------------------------------------------------------------------
+    def _smooth(self, v0, f, A, kind, nu, omega, dimension=None):
+        n = len(v0)
+        op = recognise(A, dimension)
+        plan = get_plan(op, op.g, nvec=1)
+        plan.set_shifts([0.0])
+        plan.upload(0, SLOT_V, 0, np.asarray(v0, dtype=np.float64).reshape(-1))
+        plan.upload(0, SLOT_F, 0, np.asarray(f, dtype=np.float64).reshape(-1))
+        plan.smooth(0, kind, int(nu), omega=float(omega), k=1)
+        return plan.download(0, SLOT_V, 0).reshape(n, 1)
+
+    def wjacobi(self, v0, f, A, nu=4, omega=2. / 3.):
+        """MGCMTSolver.py:182-208 — v <- (I - w D^-1 A) v + w D^-1 f, nu times; returns (n, 1)."""
+        n = len(v0)
+        _force_column(f, n)
+        _force_column(v0, n)
+        return self._smooth(v0, f, A, WJACOBI, nu, omega)
+
+    def gseidel(self, v0, f, A, nu=4):
+        """MGCMTSolver.py:210-227 — forward Gauss-Seidel in index order; returns (n, 1).  (The
+        reference only works for (n, 1) inputs; 1-D inputs are treated as columns here.)"""
+        return self._smooth(v0, f, A, GS_LEX, nu, 1.0)
+
+    def sor(self, v0, f, A, nu=4, omega=1):
+        """MGCMTSolver.py:229-246 — v <- (D-wL)^-1((1-w)D + wU) v + w (D-L)^-1 f, including the
+        reference's (D-L)^-1 on the right-hand side (:241); returns (n, 1)."""
+        return self._smooth(v0, f, A, SOR_LEX, nu, omega)
+
+    def gseidel_rb(self, v0, f, A, nu=4, omega=1.0, dimension=None):
+        """Addition — the red-black smoother the reference left as "TODO: FIX GSEIDELRB"
+        (MGCMTSolver.py:248-279): odd indices first in 1-D; in 2-D the colours (i%2, j%2) in the order
+        (0,1),(1,0),(0,0),(1,1), i.e. red-black on 5-point operators and a proper four-colour
+        Gauss-Seidel on the 9-point Galerkin operators of the coarse levels."""
+        return self._smooth(v0, f, A, GS_MC, nu, omega, dimension=dimension)
+
+    def smooth(self, v0, f, A, nu=4, smoother=None, dimension=None):
+        """Addition (named by the build's north star): dispatch on a smoother callable."""
+        kind, omega = self._resolve_smoother(smoother)
+        return self._smooth(v0, f, A, kind, nu, omega, dimension=dimension)
+
+    def _resolve_smoother(self, smoother):
+        if smoother is None:
+            return WJACOBI, 2. / 3.
+        func, kw = smoother, {}
+        if isinstance(smoother, functools.partial):
+            func, kw = smoother.func, dict(smoother.keywords or {})
+        owner, name = getattr(func, "__self__", None), getattr(func, "__name__", "")
+        if isinstance(owner, MGCMTSolver):
+            if name == "wjacobi":
+                return WJACOBI, float(kw.get("omega", 2. / 3.))
+            if name == "gseidel":
+                return GS_LEX, 1.0
+            if name == "sor":
+                return SOR_LEX, float(kw.get("omega", 1))
+            if name == "gseidel_rb":
+                return GS_MC, float(kw.get("omega", 1.0))
+        raise NotImplementedError(
+            "smoother= must be one of this class's wjacobi / gseidel / sor / gseidel_rb (optionally wrapped in "
+            "functools.partial to set omega); arbitrary Python callables cannot run inside the device V-cycle")
+
+    # ------------------------------------------------------------------------------------------
+    # cycles
+    # ------------------------------------------------------------------------------------------
+    def _grid(self, n, dimension):
+        if dimension == "1d":
+            return n
+        if dimension == "2d":
+            return np.sqrt(n)
+        return 0
+
+    def _check_grid(self, g, lowest_level):
+        """True when the cycle can run; otherwise the reference's message is printed."""
+        if g < 2:
+            print("Length of start vector is not a power of 2")
+            return False
+        if int(g) != g or not _is_pow2(g):
+            print("Old gridsize isn't a power of 2 !")     # what stencil_maker.restriction prints (:72)
+            return False
+        if lowest_level > g or not _is_pow2(lowest_level) or lowest_level < 2:
+            raise ValueError("lowest_level=%r is never reached from a grid of %d" % (lowest_level, int(g)))
+        return True
+
+    def vcycle(self, v0, f, A, stencil_maker, nu1=4, nu2=4, smoother=None, shift=0, lowest_level=2, dimension="1d",
+               *, nu_coarse=4):
+        """MGCMTSolver.py:281-329.  One V-cycle for (A - shift I) v = f.
+
+        Kept from the reference: the caller's v0/f get shape (n, 1) (:297-300); levels below the top
+        run V(4,4) because nu1/nu2 are not forwarded (:320) — ``nu_coarse`` (addition) overrides the 4;
+        the Galerkin operator is built from the unshifted A and the shift re-applied as -shift*I on
+        every level (:287-288,318); the result is 1-D (:329) except when the start grid already is the
+        lowest level, where it is (n, 1) (:305-308); bad sizes print and return None (:303-304).
+        ``stencil_maker`` is accepted for signature compatibility: the transfer operators are the
+        kernels' built-in full weighting / (bi)linear interpolation (MGCMTStencilMaker.py:27-78).
+        """
+        kind, omega = self._resolve_smoother(smoother)
+        n = len(v0)
+        g = self._grid(n, dimension)
+        _force_column(f, n)
+        _force_column(v0, n)
+        if not self._check_grid(g, lowest_level):
+            return None
+        g = int(g)
+        op = recognise(A, dimension)
+        plan = get_plan(op, int(lowest_level), nvec=1)
+        plan.set_shifts([float(shift)])
+        plan.upload(0, SLOT_V, 0, np.asarray(v0, dtype=np.float64).reshape(-1))
+        plan.upload(0, SLOT_F, 0, np.asarray(f, dtype=np.float64).reshape(-1))
+        plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=1, nu_coarse=int(nu_coarse))
+        v = plan.download(0, SLOT_V, 0)
+        if g == lowest_level:
+            return v.reshape(n, 1)
+        return v
+
+    def twogrid(self, v0, f, A, stencil_maker, nu1=4, nu2=4, smoother=None, shift=0, dimension="1d"):
+        """MGCMTSolver.py:331-371 — pre-smooth, exact solve of (R A P - shift I) on the next grid,
+        post-smooth.  (The reference sizes the coarse shift as n/2 (:350) and therefore only runs in
+        1-D; here 2-D works as well.)"""
+        kind, omega = self._resolve_smoother(smoother)
+        n = len(v0)
+        g = self._grid(n, dimension)
+        _force_column(f, n)
+        _force_column(v0, n)
+        if not self._check_grid(g, 2):
+            return None
+        g = int(g)
+        if g < 4:
+            raise ValueError("twogrid needs a fine grid of at least 4 points per direction")
+        op = recognise(A, dimension)
+        plan = get_plan(op, g // 2, nvec=1)
+        plan.set_shifts([float(shift)])
+        plan.upload(0, SLOT_V, 0, np.asarray(v0, dtype=np.float64).reshape(-1))
+        plan.upload(0, SLOT_F, 0, np.asarray(f, dtype=np.float64).reshape(-1))
+        plan.twogrid(int(nu1), int(nu2), kind, omega=omega, k=1)
+        return plan.download(0, SLOT_V, 0)
+
+    def vcycle_matrix(self, v0_matrix, f_matrix, A, stencil_maker, nu1=4, nu2=4, smoother=None, shifts=None,
+                      lowest_level=2, dimension="1d", *, nu_coarse=4):
+        """MGCMTSolver.py:375-436 — the V-cycle on k columns at once, one shift per column, modified
+        Gram-Schmidt of the columns on every non-coarsest level on the way up (:434).  All columns move
+        through every kernel together (grid z = column).  ``shifts=None`` means zero shifts (the
+        reference's default crashes)."""
+        kind, omega = self._resolve_smoother(smoother)
+        v0_matrix = np.asarray(v0_matrix, dtype=np.float64)
+        f_matrix = np.asarray(f_matrix, dtype=np.float64)
+        n = len(v0_matrix[:, 0])
+        k = f_matrix.shape[1]
+        shifts = np.zeros(k) if shifts is None else np.asarray(shifts, dtype=np.float64).reshape(-1)
+        if len(shifts) != k:
+            raise ValueError("dimension mismatch: %d shifts for %d columns" % (len(shifts), k))
+        if k > _lib.MAX_VEC:
+            raise ValueError("at most %d columns per call" % _lib.MAX_VEC)
+        g = self._grid(n, dimension)
+        if not self._check_grid(g, lowest_level):
+            return None
+        op = recognise(A, dimension)
+        plan = get_plan(op, int(lowest_level), nvec=k)
+        plan.set_shifts(shifts)
+        for i in range(k):
+            plan.upload(0, SLOT_V, i, v0_matrix[:, i])
+            plan.upload(0, SLOT_F, i, f_matrix[:, i])
+        plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=k, nu_coarse=int(nu_coarse), gram_schmidt=True)
+        v = np.zeros((n, k))
+        for i in range(k):
+            v[:, i] = plan.download(0, SLOT_V, i)
+        return v
+
+    # ------------------------------------------------------------------------------------------
+    # grid transfers as stand-alone calls (addition; the stale drivers main.py:81,163 and
+    # shiftMethod.py:77 call solver.interpolate(coarse_vec, stencil_maker, new_gridsize))
+    # ------------------------------------------------------------------------------------------
+    def interpolate(self, vec, stencil_maker, new_gridsize, dimension="1d"):
+        """stencil_maker.interpolation(old, new) * vec, computed by chaining the two-level
+        prolongation kernel (the multi-level matrix equals the product of two-level ones)."""
+        vec = np.asarray(vec, dtype=np.float64).reshape(-1)
+        old = len(vec) if dimension == "1d" else int(round(math.sqrt(len(vec))))
+        new = int(new_gridsize)
+        if not (_is_pow2(old) and _is_pow2(new) and new > old):
+            print("New gridsize isn't bigger than old gridsize !" if new <= old else "Old gridsize isn't a power of 2 !")
+            return None
+        plan = get_plan(laplacian_operator(new, dimension), old, nvec=1)
+        last = plan.num_levels - 1
+        plan.upload(last, SLOT_V, 0, vec)
+        for l in range(last - 1, -1, -1):
+            plan.prolong(l, (SLOT_V, 0), (SLOT_V, 0), accumulate=False)
+        return plan.download(0, SLOT_V, 0)
+
+    def restrict(self, vec, stencil_maker, new_gridsize, dimension="1d"):
+        """stencil_maker.restriction(old, new) * vec by chaining the full-weighting kernel; in 2-D
+        the reference's fixed 1/4 prefactor for multi-level jumps (MGCMTStencilMaker.py:77) is kept."""
+        vec = np.asarray(vec, dtype=np.float64).reshape(-1)
+        old = len(vec) if dimension == "1d" else int(round(math.sqrt(len(vec))))
+        new = int(new_gridsize)
+        if not (_is_pow2(old) and _is_pow2(new) and new < old):
+            print("New gridsize is bigger (more elements) than old gridsize !" if new >= old else "Old gridsize isn't a power of 2 !")
+            return None
+        plan = get_plan(laplacian_operator(old, dimension), new, nvec=1)
+        plan.upload(0, SLOT_V, 0, vec)
+        for l in range(plan.num_levels - 1):
+            plan.restrict(l, (SLOT_V, 0), (SLOT_V, 0))
+        out = plan.download(plan.num_levels - 1, SLOT_V, 0)
+        if dimension == "2d" and plan.num_levels > 2:
+            out *= 4.0 ** (plan.num_levels - 2)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # Rayleigh-quotient minimisation (MGCMTSolver.py:17-122)
+    # ------------------------------------------------------------------------------------------
+    _X, _P, _G, _GOLD, _AX, _AP, _MX, _MP, _TMP, _TMP2 = range(10)
+    _RQ_REGS = 10
+
+    def _rqmin_device(self, plan, level, nu):
+        """rqmin (MGCMTSolver.py:17-57) on the registers of `level`; x is register _X.  The vector
+        work (8 operator applications, ~12 inner products, 3 axpys per step) runs on the GPU; the
+        2x2 generalised eigenproblem on span{x, p} (:48-50) is solved on the host."""
+        V = SLOT_V
+        X, P, G, GOLD, AX, AP, MX, MP, TMP, TMP2 = [(V, r) for r in range(10)]
+        dot = lambda a, b: plan.dot(level, a, b)
+
+        def apply_both():
+            plan.apply(level, X, AX, op=OP_A)
+            plan.apply(level, X, MX, op=OP_M)
+
+        def gradient(rho):                       # g = 2 (A x - rho M x)
+            plan.copy(level, AX[0], AX[1], G[0], G[1])
+            plan.axpy(level, -rho, MX, G)
+            plan.scale(level, 2.0, G)
+
+        apply_both()
+        rho = dot(X, AX) / dot(X, MX)
+        plan.copy(level, X[0], X[1], GOLD[0], GOLD[1])
+        gradient(rho)
+        plan.copy(level, X[0], X[1], P[0], P[1])
+        for it in range(nu):
+            if it == 0:
+                plan.copy(level, G[0], G[1], P[0], P[1])
+                plan.scale(level, -1.0, P)
+            else:
+                plan.apply(level, G, TMP, op=OP_M)
+                plan.apply(level, GOLD, TMP2, op=OP_M)
+                beta = dot(G, TMP) / dot(GOLD, TMP2)
+                plan.scale(level, beta, P)
+                plan.axpy(level, -1.0, G, P)
+            apply_both()
+            plan.apply(level, P, AP, op=OP_A)
+            plan.apply(level, P, MP, op=OP_M)
+            R = np.array([[dot(X, AX), dot(X, AP)], [dot(P, AX), dot(P, AP)]])
+            RM = np.array([[dot(X, MX), dot(X, MP)], [dot(P, MX), dot(P, MP)]])
+            w, vecs = scipy.linalg.eig(R, b=RM)
+            y = vecs[:, np.argmin(w)]
+            delta = float(np.real(y[1] / y[0]))
+            plan.axpy(level, delta, P, X)
+            apply_both()
+            rho = dot(X, AX) / dot(X, MX)
+            plan.copy(level, G[0], G[1], GOLD[0], GOLD[1])
+            gradient(rho)
+        return rho
+
+    def _rq_plan(self, A, M, nmin, dimension=None):
+        if M is None:
+            raise AttributeError("'NoneType' object has no attribute 'dot'")      # what the reference raises (:19)
+        opA = recognise(A, dimension)
+        opM = recognise(M, opA.dimension)
+        return get_plan(opA, int(nmin), nvec=self._RQ_REGS, mass=opM)
+
+    def rqmin(self, A, v0, M=None, nu=4):
+        """MGCMTSolver.py:17-57 — returns (x, rho).  (The reference's x / rho are complex-typed with
+        zero imaginary part because scipy's eig returns complex; real values are returned here.)"""
+        if M is None:
+            raise AttributeError("'NoneType' object has no attribute 'dot'")      # what the reference raises (:19)
+        x0 = np.asarray(v0, dtype=np.float64).reshape(-1)
+        opA = recognise(A)
+        plan = get_plan(opA, opA.g, nvec=self._RQ_REGS, mass=recognise(M, opA.dimension))
+        plan.set_shifts(np.zeros(self._RQ_REGS))
+        plan.upload(0, SLOT_V, self._X, x0)
+        rho = self._rqmin_device(plan, 0, int(nu))
+        return plan.download(0, SLOT_V, self._X), rho
+
+    def _rqmg_levels(self, plan, level, nu1, nu2):
+        rho = self._rqmin_device(plan, level, nu1)
+        if level + 1 < plan.num_levels:
+            plan.restrict(level, (SLOT_V, self._X), (SLOT_V, self._X))             # k_coarse = R k   (:113)
+            _, rho = self._rqmg_levels(plan, level + 1, nu1, nu2)
+            plan.prolong(level, (SLOT_V, self._X), (SLOT_V, self._X), accumulate=True)  # k += P c   (:116-118)
+            rho = self._rqmin_device(plan, level, nu2)
+        return None, rho
+
+    def vcycle_rqmg(self, x, A, M, nu1=4, nu2=4, nmin=2):
+        """MGCMTSolver.py:99-122 — Rayleigh-quotient multigrid: rqmin, restrict the ITERATE, recurse
+        on the Galerkin pair (R A P, R M P), add the interpolated coarse iterate, rqmin; returns (k, rho)."""
+        x0 = np.asarray(x, dtype=np.float64).reshape(-1)
+        n = len(x0)
+        plan = self._rq_plan(A, M, max(int(nmin), 2) if n > nmin else n)
+        plan.set_shifts(np.zeros(self._RQ_REGS))
+        plan.upload(0, SLOT_V, self._X, x0)
+        _, rho = self._rqmg_levels(plan, 0, int(nu1), int(nu2))
+        return plan.download(0, SLOT_V, self._X), rho
+
+    def vcycle_rqmg2(self, x_matrix, A, M, nu1=4, nu2=4, nmin=2, level=0):
+        """MGCMTSolver.py:59-94 — multi-vector variant: rqmin per column, four Gram-Schmidt passes on
+        the finest level (:69-71), recursion on the restricted columns, correction and rqmin per column."""
+        k0 = np.array(x_matrix, dtype=np.float64)
+        n, nv = k0.shape
+        if nv > _lib.MAX_VEC:
+            raise ValueError("at most %d columns per call" % _lib.MAX_VEC)
+        opA = recognise(A)
+        plan = get_plan(opA, max(int(nmin), 2) if n > nmin else n, nvec=max(self._RQ_REGS, nv), mass=recognise(M, opA.dimension))
+        plan.set_shifts(np.zeros(plan.nvec))
+        for i in range(nv):
+            plan.upload(0, SLOT_W, i, k0[:, i])
+        self._rqmg2_levels(plan, 0, nv, int(nu1), int(nu2))
+        out = np.zeros((n, nv))
+        for i in range(nv):
+            out[:, i] = plan.download(0, SLOT_W, i)
+        return out
+
+    def _rqmg2_levels(self, plan, level, nv, nu1, nu2):
+        for i in range(nv):
+            plan.copy(level, SLOT_W, i, SLOT_V, self._X)
+            self._rqmin_device(plan, level, nu1)
+            plan.copy(level, SLOT_V, self._X, SLOT_W, i)
+        if level == 0:
+            for _ in range(4):
+                plan.gramschmidt(level, SLOT_W, nv, modified=1)
+        if level + 1 < plan.num_levels:
+            for i in range(nv):
+                plan.restrict(level, (SLOT_W, i), (SLOT_W, i))
+            self._rqmg2_levels(plan, level + 1, nv, nu1, nu2)
+            for i in range(nv):
+                plan.prolong(level, (SLOT_W, i), (SLOT_W, i), accumulate=True)
+                plan.copy(level, SLOT_W, i, SLOT_V, self._X)
+                self._rqmin_device(plan, level, nu2)
+                plan.copy(level, SLOT_V, self._X, SLOT_W, i)
+
+    def twogridrqmin(self, A, v0, M, nu1=4, nu2=4):
+        """MGCMTSolver.py:127-178 is dead code in the reference (it calls ``eigh`` which is never
+        imported, :167 vs :4, and raises NameError on first use)."""
+        raise NameError("name 'eigh' is not defined")
