@@ -5,8 +5,9 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hip_cpu_mock")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -19,11 +20,42 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
-@pytest.fixture
-def golden():
-    return load_golden
-
-
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
     return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+
+
+_bound = {"kind": None}
+
+
+def bind_backend(kind):
+    """Point the ctypes binding at the real HIP library ("hip") or at the host-only emulation build
+    of the same kernel sources ("emu", tests/hip_cpu_mock).  Only tests do this."""
+    from multigridcmt_amd import _lib, plan
+    if _bound["kind"] == kind:
+        return
+    plan.release_plans()
+    if kind == "hip":
+        if not os.path.exists(_lib.DEFAULT_LIBRARY):
+            pytest.fail("libmgcmt_hip.so is not built — run __graft_entry__.build()")
+        _lib.use_library(_lib.DEFAULT_LIBRARY)
+        if _lib.device_count() < 1:
+            pytest.fail("no HIP device visible")
+    else:
+        import build_emu
+        _lib.use_library(build_emu.build())
+    _bound["kind"] = kind
+
+
+@pytest.fixture(params=[pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    """Every parity test runs twice: through the HIP library on the GPU box (-m gpu) and through the
+    emulated kernels on CPU (-m "not gpu") so kernel logic regressions show up without a GPU."""
+    bind_backend(request.param)
+    return request.param
+
+
+@pytest.fixture
+def hip_only():
+    bind_backend("hip")
+    return "hip"
