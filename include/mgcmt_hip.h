@@ -35,7 +35,7 @@ extern "C" {
 
 #define MGCMT_ABI_VERSION 1
 #define MGCMT_MAX_TERMS 4
-#define MGCMT_HALO_ROWS 4 /* rows of halo kept above and below every level's vectors */
+#define MGCMT_HALO_ROWS 8 /* rows of halo kept above and below every level's vectors */
 
 typedef enum mgcmt_status {
   MGCMT_OK = 0,
@@ -138,10 +138,20 @@ int mgcmt_gramschmidt(mgcmt_plan* plan, int level, int slot, int k, int modified
 /* columns scaled to unit 2-norm (normalize, :52-63) */
 int mgcmt_normalize(mgcmt_plan* plan, int level, int slot, int k, void* stream);
 
+/* plan options: MGCMT_OPT_FUSED (default 1) selects the fused row-streaming kernels on large constant-
+ * coefficient levels; 0 forces the one-launch-per-operation kernels everywhere (A/B checks) */
+typedef enum mgcmt_option { MGCMT_OPT_FUSED = 0, MGCMT_OPT_FUSED_ROWS = 1 /* tuning: rows per wave chunk, 0 = auto */ } mgcmt_option;
+int mgcmt_plan_set_option(mgcmt_plan* plan, int option, int value);
+
 /* timing of the dominant kernel for bench.py: runs `reps` fine-level smoother sweeps between two
  * HIP events on `stream` and returns the elapsed milliseconds */
 int mgcmt_time_smoother(mgcmt_plan* plan, int level, int kind, int nu, double omega, int reps, double* ms_out,
                         void* stream);
+
+/* empirical HBM ceilings for bench.py: streams the plan's level-`level` vectors (slots V, F -> T) with a
+ * plain grid-stride kernel; kind 0 copy (16 B/point), 1 triad (24 B/point), 2 read-only (8 B/point);
+ * returns the average milliseconds per launch */
+int mgcmt_bandwidth_probe(mgcmt_plan* plan, int level, int kind, int blocks, int reps, double* ms_out, void* stream);
 
 #ifdef __cplusplus
 }

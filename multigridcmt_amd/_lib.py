@@ -15,10 +15,12 @@ DEFAULT_LIBRARY = os.path.join(_HERE, "libmgcmt_hip.so")
 WJACOBI, GS_LEX, SOR_LEX, GS_MC = 0, 1, 2, 3
 SLOT_V, SLOT_F, SLOT_T, SLOT_W = 0, 1, 2, 3
 OP_A, OP_M = 0, 1
-HALO_ROWS = 4
+HALO_ROWS = 8
 MAX_TERMS = 4
 MAX_VEC = 32
 ABI_VERSION = 1
+OPT_FUSED = 0
+OPT_FUSED_ROWS = 1
 
 
 class MgcmtError(RuntimeError):
@@ -67,6 +69,8 @@ _SIGNATURES = {
     "mgcmt_scale": (c_int, [c_void_p, c_int, c_double, c_int, c_int, c_void_p]),
     "mgcmt_gramschmidt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mgcmt_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mgcmt_plan_set_option": (c_int, [c_void_p, c_int, c_int]),
+    "mgcmt_bandwidth_probe": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _dp, c_void_p]),
     "mgcmt_time_smoother": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, _dp, c_void_p]),
 }
 

@@ -74,6 +74,25 @@ __global__ void __launch_bounds__(kRedThreads) k_dot_final(int nblocks, const do
   if (threadIdx.x == 0) out[q] = t;
 }
 
+// bandwidth probes (bench.py's empirical HBM ceilings): 16-byte accesses, grid-stride
+__global__ void k_probe_copy(long n2, const double2* __restrict__ a, double2* __restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) out[i] = a[i];
+}
+__global__ void k_probe_triad(long n2, const double2* __restrict__ a, const double2* __restrict__ b, double2* __restrict__ out, double s) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+    const double2 x = a[i], y = b[i];
+    out[i] = make_double2(x.x + s * y.x, x.y + s * y.y);
+  }
+}
+__global__ void k_probe_read(long n2, const double2* __restrict__ a, double* __restrict__ sink) {
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+    const double2 x = a[i];
+    acc += x.x + x.y;
+  }
+  if (acc == 12345.678) sink[0] = acc;  // keeps the loads alive without a store stream
+}
+
 inline unsigned blocks_for(long n) {
   long b = (n + 255) / 256;
   if (b > 2048) b = 2048;
@@ -97,6 +116,13 @@ void launch_axpy_dev(hipStream_t s, long n, const double* alpha_dev, const doubl
 
 void launch_scale_dev(hipStream_t s, long n, const double* s_dev, int use_sqrt, double* x) {
   hipLaunchKernelGGL(k_scale_dev, dim3(blocks_for(n)), dim3(256), 0, s, n, s_dev, use_sqrt, x);
+}
+
+void launch_probe(hipStream_t s, int kind, long n, const double* a, const double* b, double* out, int blocks) {
+  const long n2 = n / 2;
+  if (kind == 0) hipLaunchKernelGGL(k_probe_copy, dim3(blocks), dim3(256), 0, s, n2, (const double2*)a, (double2*)out);
+  else if (kind == 1) hipLaunchKernelGGL(k_probe_triad, dim3(blocks), dim3(256), 0, s, n2, (const double2*)a, (const double2*)b, (double2*)out, 0.5);
+  else hipLaunchKernelGGL(k_probe_read, dim3(blocks), dim3(256), 0, s, n2, (const double2*)a, out);
 }
 
 int reduce_blocks(long n) {

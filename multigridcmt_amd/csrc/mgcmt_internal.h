@@ -24,6 +24,11 @@ struct KOp {
   const double* Y[kMaxTerms];
   long ldx, ldy;
   double c0, cn, cw;  // centre, row-neighbour, column-neighbour coefficient (five_point only)
+  // nine_const: every factor is Toeplitz except its last diagonal entry (Galerkin levels of a constant
+  // operator): interior coefficients c9[di+1][dj+1], own-row coefficients on the last row, centre-column
+  // coefficients on the last column, and the corner's diagonal
+  int nine_const;
+  double c9[3][3], c9row[3], c9col[3], c9corner;
 };
 
 // A batch of vectors on one level: interior pointer of vector 0, elements between vectors.
@@ -51,6 +56,15 @@ void launch_prolong(hipStream_t s, KGrid fine, KGrid coarse, KVec e, KVec v, int
 void launch_lex_sweep(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta,
                       double wU, double wL, int k);
 
+// fused row-streaming passes (kernels_fused.hip): vin -> vout with nsweep sweeps of weighted Jacobi or
+// multicolour Gauss-Seidel; mode 0 plain, 1 prolong+correct first (coarse = correction), 2 residual+restrict
+// last (coarse = right-hand side)
+bool fused_supported(const KGrid& g, const KOp& op);
+int fused_max_sweeps(const KOp& op, int multicolour);
+void fused_set_rows(long rows);  // tuning: rows per chunk, 0 = automatic
+void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
+                  double omega, int multicolour, int nsweep, int mode, long row_lo, long row_hi, long last_row, int k);
+
 // vector algebra; scalar results / inputs live in device memory so nothing syncs with the host
 void launch_fill(hipStream_t s, double* p, long n, double value);
 // y += (alpha_scale * alpha_dev[0] / (den_dev ? den_dev[0] : 1)) * x ;  x /= (use_sqrt ? sqrt(s_dev[0]) : s_dev[0])
@@ -58,6 +72,8 @@ void launch_axpy_dev(hipStream_t s, long n, const double* alpha_dev, const doubl
 void launch_scale_dev(hipStream_t s, long n, const double* s_dev, int use_sqrt, double* x);
 void launch_axpy(hipStream_t s, long n, double alpha, const double* x, double* y);
 void launch_scale(hipStream_t s, long n, double alpha, double* x);
+// streaming probes: kind 0 copy (a -> out), 1 triad (a + s b -> out), 2 read-only (a)
+void launch_probe(hipStream_t s, int kind, long n, const double* a, const double* b, double* out, int blocks);
 // out[q] = <x, y_q> for q < nq (y_q = y + q*ystride), deterministic two-pass reduction; `partials`
 // holds at least nq * reduce_blocks(n) doubles
 int reduce_blocks(long n);

@@ -130,6 +130,7 @@ struct mgcmt_plan {
   double* d_scalars = nullptr;  // [4*kMaxVec] reduction results
   std::vector<double> h_shifts;
   bool has_mass = false;
+  bool use_fused = true;
 
   KGrid kgrid(int l) const {
     KGrid kg = levels[l].grid();
@@ -199,6 +200,45 @@ int upload_op(const HostOp& h, const Level& L, int dim, DevOp* d) {
     k.cn = c[0][1];
     k.cw = c[1][0];
   }
+  // Galerkin levels of a constant operator: Toeplitz factors whose last diagonal entry differs
+  if (!k.five_point && dim == 2 && h.nterms > 0) {
+    auto toeplitz_but_last = [](const Tri& t, double* lo, double* di, double* up, double* last) {
+      if (t.n < 3) return false;
+      *di = t.di(0);
+      *lo = t.lo(1);
+      *up = t.up(0);
+      *last = t.di(t.n - 1);
+      for (int64_t i = 0; i < t.n; ++i) {
+        if (i + 1 < t.n && t.di(i) != *di) return false;
+        if (i > 0 && t.lo(i) != *lo) return false;
+        if (i + 1 < t.n && t.up(i) != *up) return false;
+      }
+      return true;
+    };
+    bool ok = true;
+    double c9[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, crow[3] = {0, 0, 0}, ccol[3] = {0, 0, 0}, corner = 0;
+    for (int m = 0; m < h.nterms && ok; ++m) {
+      double x[3], y[3], xl, yl;
+      ok = toeplitz_but_last(h.X[m], &x[0], &x[1], &x[2], &xl) && toeplitz_but_last(h.Y[m], &y[0], &y[1], &y[2], &yl);
+      if (!ok) break;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) c9[a][b] += x[a] * y[b];
+      for (int b = 0; b < 3; ++b) crow[b] += xl * y[b];   // last row: X's diagonal entry is the modified one
+      for (int a = 0; a < 3; ++a) ccol[a] += x[a] * yl;   // last column: Y's diagonal entry is the modified one
+      corner += xl * yl;
+      crow[1] += 0.0;
+    }
+    if (ok) {
+      // on the last row the centre coefficient of the last column is the corner; crow[1] is the centre elsewhere
+      k.nine_const = 1;
+      for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) k.c9[a][b] = c9[a][b];
+        k.c9row[a] = crow[a];
+        k.c9col[a] = ccol[a];
+      }
+      k.c9corner = corner;
+    }
+  }
   return MGCMT_OK;
 }
 
@@ -240,12 +280,47 @@ int post_launch() {
 
 // ---- smoothers --------------------------------------------------------------------------------
 
+// one fused row-streaming pass V -> T (then swapped) on a constant 5-point level
+int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, hipStream_t s) {
+  Level& L = p->levels[l];
+  KVec coarse{nullptr, 0};
+  long cnc = 0;
+  if (mode != 0) {
+    coarse = p->kvec(l + 1, mode == 1 ? MGCMT_SLOT_V : MGCMT_SLOT_F);
+    cnc = p->levels[l + 1].gc;
+  }
+  const long row_lo = L.r0 == 0 ? 0 : -kHalo;
+  const long row_hi = L.r0 + L.nr == L.gr ? L.nr : L.nr + kHalo;
+  launch_fused(s, p->kgrid(l), L.dA.k, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_T), coarse, cnc,
+               p->d_shifts, omega, kind == MGCMT_GS_MC ? 1 : 0, nsweep, mode, row_lo, row_hi, L.gr - 1 - L.r0, k);
+  std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
+  return MGCMT_OK;
+}
+
+bool fused_level(const mgcmt_plan* p, int l, int kind) {
+  return p->use_fused && (kind == MGCMT_WJACOBI || kind == MGCMT_GS_MC) && fused_supported(p->kgrid(l), p->levels[l].dA.k);
+}
+
+int pass_sweeps(const mgcmt_plan* p, int l, int kind, int left) {
+  const int cap = fused_max_sweeps(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0);
+  return left < cap ? left : cap;
+}
+
 int smooth_impl(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hipStream_t s) {
   Level& L = p->levels[l];
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
   const KGrid g = p->kgrid(l);
   const KOp& op = L.dA.k;
+  if (fused_level(p, l, kind)) {
+    MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
+    for (int left = nu; left > 0;) {
+      const int n = pass_sweeps(p, l, kind, left);
+      MG_TRY(fused_pass(p, l, kind, n, omega, 0, k, s));
+      left -= n;
+    }
+    return post_launch();
+  }
   switch (kind) {
     case MGCMT_WJACOBI: {
       MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
@@ -337,6 +412,50 @@ int coarse_solve_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
   }
   launch_band_solve(s, B.b, p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_V), k);
   return post_launch();
+}
+
+// pre-smoothing + residual + restriction (MGCMTSolver.py:313-316); one pass less on fused levels
+int down_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hipStream_t s) {
+  if (nu >= 1 && fused_level(p, l, kind)) {
+    MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
+    MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
+    MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
+    MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
+    MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_F));
+    int left = nu;
+    while (left > pass_sweeps(p, l, kind, left)) {
+      const int n = pass_sweeps(p, l, kind, left);
+      MG_TRY(fused_pass(p, l, kind, n, omega, 0, k, s));
+      left -= n;
+    }
+    MG_TRY(fused_pass(p, l, kind, left, omega, 2, k, s));
+    for (int q = 0; q < k; ++q) launch_fill(s, p->kvec(l + 1, MGCMT_SLOT_V, q).p, p->interior(l + 1), 0.0);
+    return post_launch();
+  }
+  MG_TRY(smooth_impl(p, l, kind, nu, omega, k, s));
+  return residual_restrict_impl(p, l, k, s);
+}
+
+// prolongation + correction + post-smoothing (MGCMTSolver.py:323-326)
+int up_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hipStream_t s) {
+  if (nu >= 1 && fused_level(p, l, kind)) {
+    MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
+    MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
+    MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
+    MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
+    int left = nu;
+    const int first = pass_sweeps(p, l, kind, left);
+    MG_TRY(fused_pass(p, l, kind, first, omega, 1, k, s));
+    left -= first;
+    while (left > 0) {
+      const int n = pass_sweeps(p, l, kind, left);
+      MG_TRY(fused_pass(p, l, kind, n, omega, 0, k, s));
+      left -= n;
+    }
+    return post_launch();
+  }
+  MG_TRY(prolong_correct_impl(p, l, k, s));
+  return smooth_impl(p, l, kind, nu, omega, k, s);
 }
 
 // ---- Gram-Schmidt -------------------------------------------------------------------------------
@@ -636,14 +755,10 @@ int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int 
   MG_TRY(check_k(p, k));
   const int last = (int)p->levels.size() - 1;
   hipStream_t s = S(stream);
-  for (int l = level; l < last; ++l) {
-    MG_TRY(smooth_impl(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, s));
-    MG_TRY(residual_restrict_impl(p, l, k, s));
-  }
+  for (int l = level; l < last; ++l) MG_TRY(down_leg(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, s));
   MG_TRY(coarse_solve_impl(p, last, k, s));
   for (int l = last - 1; l >= level; --l) {
-    MG_TRY(prolong_correct_impl(p, l, k, s));
-    MG_TRY(smooth_impl(p, l, kind, l == level ? nu2 : nu_coarse, omega, k, s));
+    MG_TRY(up_leg(p, l, kind, l == level ? nu2 : nu_coarse, omega, k, s));
     if (gram_schmidt) MG_TRY(gramschmidt_impl(p, l, MGCMT_SLOT_V, k, 1, s));
   }
   return MGCMT_OK;
@@ -654,11 +769,9 @@ int mgcmt_twogrid(mgcmt_plan* p, int level, int nu1, int nu2, int kind, double o
   MG_TRY(check_k(p, k));
   if (level + 1 >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "twogrid needs a coarser level");
   hipStream_t s = S(stream);
-  MG_TRY(smooth_impl(p, level, kind, nu1, omega, k, s));
-  MG_TRY(residual_restrict_impl(p, level, k, s));
+  MG_TRY(down_leg(p, level, kind, nu1, omega, k, s));
   MG_TRY(coarse_solve_impl(p, level + 1, k, s));
-  MG_TRY(prolong_correct_impl(p, level, k, s));
-  MG_TRY(smooth_impl(p, level, kind, nu2, omega, k, s));
+  MG_TRY(up_leg(p, level, kind, nu2, omega, k, s));
   return MGCMT_OK;
 }
 
@@ -740,6 +853,19 @@ int mgcmt_normalize(mgcmt_plan* p, int l, int slot, int k, void* stream) {
   return post_launch();
 }
 
+int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
+  if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
+  if (option == MGCMT_OPT_FUSED) {
+    p->use_fused = value != 0;
+    return MGCMT_OK;
+  }
+  if (option == MGCMT_OPT_FUSED_ROWS) {
+    fused_set_rows(value);
+    return MGCMT_OK;
+  }
+  return fail(MGCMT_ERR_INVALID, "unknown option");
+}
+
 int mgcmt_time_smoother(mgcmt_plan* p, int l, int kind, int nu, double omega, int reps, double* ms_out, void* stream) {
   MG_TRY(check_level(p, l));
   if (!ms_out || reps < 1) return fail(MGCMT_ERR_INVALID, "bad arguments");
@@ -756,6 +882,30 @@ int mgcmt_time_smoother(mgcmt_plan* p, int l, int kind, int nu, double omega, in
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   return MGCMT_OK;
+}
+
+int mgcmt_bandwidth_probe(mgcmt_plan* p, int l, int kind, int blocks, int reps, double* ms_out, void* stream) {
+  MG_TRY(check_level(p, l));
+  if (!ms_out || reps < 1 || blocks < 1 || kind < 0 || kind > 2) return fail(MGCMT_ERR_INVALID, "bad arguments");
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
+  const long n = p->interior(l) & ~1L;
+  hipEvent_t a, b;
+  MG_HIP(hipEventCreate(&a));
+  MG_HIP(hipEventCreate(&b));
+  launch_probe(S(stream), kind, n, p->kvec(l, MGCMT_SLOT_V).p, p->kvec(l, MGCMT_SLOT_F).p, p->kvec(l, MGCMT_SLOT_T).p, blocks);
+  MG_HIP(hipEventRecord(a, S(stream)));
+  for (int r = 0; r < reps; ++r)
+    launch_probe(S(stream), kind, n, p->kvec(l, MGCMT_SLOT_V).p, p->kvec(l, MGCMT_SLOT_F).p, p->kvec(l, MGCMT_SLOT_T).p, blocks);
+  MG_HIP(hipEventRecord(b, S(stream)));
+  MG_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  MG_HIP(hipEventElapsedTime(&ms, a, b));
+  *ms_out = (double)ms / reps;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return post_launch();
 }
 
 }  // extern "C"

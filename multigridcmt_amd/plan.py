@@ -155,6 +155,14 @@ class Plan:
     def normalize(self, level, slot, k, stream=None):
         check(_lib.lib().mgcmt_normalize(self._h, level, slot, k, stream))
 
+    def set_option(self, option, value):
+        check(_lib.lib().mgcmt_plan_set_option(self._h, option, int(value)))
+
+    def bandwidth_probe(self, level, kind, blocks, reps, stream=None):
+        ms = c_double(0.0)
+        check(_lib.lib().mgcmt_bandwidth_probe(self._h, level, kind, blocks, reps, ctypes.byref(ms), stream))
+        return ms.value
+
     def time_smoother(self, level, kind, nu, omega, reps, stream=None):
         ms = c_double(0.0)
         check(_lib.lib().mgcmt_time_smoother(self._h, level, kind, nu, c_double(omega), reps, ctypes.byref(ms), stream))

@@ -40,6 +40,10 @@ struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+struct double2 {
+  double x, y;
+};
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
 struct hipDeviceProp_t {
   char name[256];
   char gcnArchName[256];
@@ -111,6 +115,12 @@ hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKin
 hipError_t hipMemset(void* dst, int value, size_t bytes);
 hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s);
 hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
+template <typename F>
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* blocks, F, int, size_t) {
+  *blocks = 2;
+  return hipSuccess;
+}
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int device);
 const char* hipGetErrorString(hipError_t e);

@@ -138,6 +138,10 @@ hipError_t hipMemset(void* dst, int value, size_t bytes) {
 }
 hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t) { return hipMemset(dst, value, bytes); }
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) {
+  *d = 0;
+  return hipSuccess;
+}
 hipError_t hipGetDeviceCount(int* n) {
   *n = 1;
   return hipSuccess;
@@ -146,7 +150,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int) {
   memset(prop, 0, sizeof(*prop));
   snprintf(prop->name, sizeof(prop->name), "hipmock CPU emulator");
   snprintf(prop->gcnArchName, sizeof(prop->gcnArchName), "cpu-fibers");
-  prop->multiProcessorCount = 1;
+  prop->multiProcessorCount = 4;
   return hipSuccess;
 }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "hipmock error"; }

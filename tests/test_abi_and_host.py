@@ -1,0 +1,100 @@
+"""CPU tests of the boundary and the host logic: every symbol declared in include/mgcmt_hip.h is exported
+by libmgcmt_hip.so (loaded, not executed: no GPU here), the StencilMaker matrices equal the reference's,
+and operator recognition maps the reference's sparse matrices to Kronecker factors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import ROOT, load_golden
+from multigridcmt_amd import MGCMTStencilMaker, _lib
+from multigridcmt_amd.operators import StructuredOperator, UnrecognisedOperator, laplacian_operator, recognise
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mgcmt_hip.h")).read()
+    return sorted(set(re.findall(r"\b(mgcmt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_lib.EXPORTED_SYMBOLS)
+
+
+def test_hip_library_exports_every_declared_symbol():
+    path = _lib.DEFAULT_LIBRARY
+    assert os.path.exists(path), "libmgcmt_hip.so missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(path)                      # loading needs no GPU
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    lib.mgcmt_abi_version.restype = ctypes.c_int
+    assert lib.mgcmt_abi_version() == _lib.ABI_VERSION
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_lib_path", None)
+    monkeypatch.setattr(_lib, "DEFAULT_LIBRARY", "/nonexistent/libmgcmt_hip.so")
+    with pytest.raises(_lib.MgcmtError):
+        _lib.lib()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "multigridcmt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in text.replace("the oracle's", ""), os.path.join(dirpath, fn)
+
+
+def test_stencil_maker_matrices_equal_reference():
+    sm, g = MGCMTStencilMaker(), load_golden("operators")
+    assert np.array_equal(sm.restriction(16, 8).toarray(), g["R_16_8"])
+    assert np.array_equal(sm.interpolation(8, 16).toarray(), g["P_8_16"])
+    assert np.array_equal(sm.interpolation(4, 16).toarray(), g["P_4_16"])
+    assert np.array_equal(sm.restriction(16, 4).toarray(), g["R_16_4"])
+    assert np.array_equal(sm.interpolation(4, 8, dimension="2d").toarray(), g["P2d_4_8"])
+    assert np.array_equal(sm.restriction(8, 4, dimension="2d").toarray(), g["R2d_8_4"])
+    assert np.array_equal(sm.restriction(16, 4, dimension="2d").toarray(), g["R2d_16_4"])      # fixed 1/4 quirk
+    assert np.array_equal(sm.interpolation(4, 16, dimension="2d").toarray(), g["P2d_4_16"])
+    assert np.array_equal(sm.laplacian(8).toarray(), g["L1d_8"])
+    assert np.array_equal(sm.laplacian(4, dimension="2d").toarray(), g["L2d_4"])
+    assert sm.laplacian(8).format == "csc"
+
+
+def test_stencil_maker_error_convention(capsys):
+    sm = MGCMTStencilMaker()
+    assert sm.interpolation(8, 4) is None and sm.interpolation(6, 16) is None and sm.interpolation(4, 12) is None
+    assert sm.restriction(4, 8) is None and sm.restriction(12, 4) is None
+    out = capsys.readouterr().out
+    assert "New gridsize isn't bigger than old gridsize !" in out and "Old gridsize isn't a power of 2 !" in out
+
+
+def test_recognise_reference_operators():
+    sm = MGCMTStencilMaker()
+    op = recognise((-1 / np.pi ** 2) * sm.laplacian(16))
+    assert op.dimension == "1d" and op.g == 16
+    assert np.allclose(op.tocsr().toarray(), ((-1 / np.pi ** 2) * sm.laplacian(16)).toarray(), rtol=0, atol=0)
+    A2 = (-1 / np.pi ** 2) * sm.laplacian(8, dimension="2d") - 1.7 * sp.eye(64)
+    op2 = recognise(A2, "2d")
+    assert op2.dimension == "2d" and np.abs(op2.tocsr().toarray() - A2.toarray()).max() < 1e-13
+    V = np.add.outer(np.arange(8.0), 2 * np.arange(8.0)).ravel()                  # separable potential
+    op3 = recognise(sm.laplacian(8, dimension="2d") + sp.diags(V), "2d")
+    assert np.abs(op3.tocsr().toarray() - (sm.laplacian(8, dimension="2d") + sp.diags(V)).toarray()).max() < 1e-12
+    with pytest.raises(UnrecognisedOperator):
+        recognise(sm.laplacian(8, dimension="2d") + sp.diags(np.random.RandomState(0).rand(64)), "2d")
+    with pytest.raises(UnrecognisedOperator):
+        recognise(sp.random(64, 64, density=0.2, random_state=0) + sp.eye(64), "2d")
+
+
+def test_structured_operator_algebra():
+    op = laplacian_operator(8, "2d")
+    sm = MGCMTStencilMaker()
+    assert np.array_equal(op.tocsr().toarray(), sm.laplacian(8, dimension="2d").toarray())
+    assert np.allclose(((-0.5) * op).toarray(), -0.5 * sm.laplacian(8, dimension="2d").toarray())
+    assert np.allclose(op.shifted(2.0).toarray(), (sm.laplacian(8, dimension="2d") - 2.0 * sp.eye(64)).toarray())
+    assert np.allclose(op.diagonal(), sm.laplacian(8, dimension="2d").diagonal())
+    assert isinstance(sm.laplacian(8, dimension="2d", matrix_free=True), StructuredOperator)

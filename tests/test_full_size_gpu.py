@@ -1,0 +1,71 @@
+"""GPU-only checks at BASELINE.json's sizes, through size-independent properties (the oracle cannot run
+a 16384^2 cycle in seconds): fused == unfused kernels, linearity of the smoother, and per-cycle residual
+reduction equal to what the C oracle shows at a size it can run."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from multigridcmt_amd import _lib
+from multigridcmt_amd.operators import laplacian_operator
+from multigridcmt_amd.plan import Plan
+from oracle import structured as st
+
+pytestmark = pytest.mark.gpu
+SCALE = -1 / np.pi ** 2
+
+
+def _residual_norm(p, n):
+    p.apply(0, (_lib.SLOT_V, 0), (_lib.SLOT_W, 0), with_shift=True)
+    p.axpy(0, -1.0, (_lib.SLOT_F, 0), (_lib.SLOT_W, 0))
+    return np.sqrt(p.dot(0, (_lib.SLOT_W, 0), (_lib.SLOT_W, 0)))
+
+
+@pytest.mark.parametrize("kind,omega", [(_lib.WJACOBI, 2. / 3.), (_lib.GS_MC, 1.0)])
+def test_config2_4096_fused_equals_unfused_and_converges(hip_only, kind, omega):
+    g = 4096
+    f = np.random.RandomState(1).rand(g * g)
+    outs, hist = [], []
+    for fused in (1, 0):
+        p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
+        p.set_option(_lib.OPT_FUSED, fused)
+        p.set_shifts([0.0])
+        p.upload(0, _lib.SLOT_F, 0, f)
+        p.fill(0, _lib.SLOT_V, 0, 0.0)
+        r = [np.linalg.norm(f)]
+        for _ in range(4):
+            p.vcycle(2, 2, kind, omega=omega, nu_coarse=2)
+            r.append(_residual_norm(p, g * g))
+        outs.append(p.download(0, _lib.SLOT_V, 0))
+        hist.append(r)
+        p.close()
+    assert rel_err(outs[0], outs[1]) < 1e-10
+    factors = [hist[0][i + 1] / hist[0][i] for i in range(4)]
+    assert all(fac < 0.35 for fac in factors), factors            # V(2,2) contracts the residual every cycle
+    # the same cycle on a grid the C oracle finishes in seconds reduces the residual at the same rate
+    go = 1024
+    X, Y = st.laplacian_factors(go, "2d", SCALE)
+    fo = np.random.RandomState(1).rand(go * go)
+    v = np.zeros(go * go)
+    ro = [np.linalg.norm(fo)]
+    for _ in range(4):
+        v = st.vcycle(X, Y, go, 8, 0.0, st.WJACOBI if kind == _lib.WJACOBI else st.GS_MC, v, fo, 2, 2, 2, omega)
+        ro.append(np.linalg.norm(st.residual(X, Y, 0.0, v, fo)))
+    assert abs(ro[4] / ro[3] - factors[3]) < 0.05
+
+
+def test_config3_16384_jacobi_linearity(hip_only):
+    """wjacobi with f = 0 is linear: S(a x + b y) = a S(x) + b S(y), checked at the headline size."""
+    g = 16384
+    p = Plan(laplacian_operator(g, "2d") * SCALE, g, nvec=3)
+    p.set_shifts([0.0, 0.0, 0.0])
+    rng = np.random.RandomState(5)
+    x, y = rng.rand(g * g), rng.rand(g * g)
+    p.upload(0, _lib.SLOT_V, 0, x)
+    p.upload(0, _lib.SLOT_V, 1, y)
+    p.upload(0, _lib.SLOT_V, 2, 2.0 * x - 0.5 * y)
+    for q in range(3):
+        p.fill(0, _lib.SLOT_F, q, 0.0)
+    p.smooth(0, _lib.WJACOBI, 4, 2. / 3., k=3)
+    sx, sy, sz = (p.download(0, _lib.SLOT_V, q) for q in range(3))
+    p.close()
+    assert rel_err(sz, 2.0 * sx - 0.5 * sy) < 1e-13
