@@ -132,39 +132,39 @@ struct Op9c {
   double rw, rc, re;                                     // own-row coefficients on the last row
   double kn, kc, ks, kcr;                                // centre-column coefficients on the last column (kcr: corner)
   double mu;
-  double w_, c_, e_;  // own-row coefficients of the row being updated
-  bool last_row, last_col_b;
+  double lastb;  // 1.0 when column ja+1 is the last column, else 0.0 (arithmetic blends, no data-dependent selects of members)
   long last_row_index;
+  double lr;     // 1.0 on the last row
+  double i00, ir, ic, irc;
   __device__ __forceinline__ void init(const FusedArgs& a, int q, long ja, long nc) {
     cnw = a.c9[0][0]; cn_ = a.c9[0][1]; cne = a.c9[0][2];
     cw_ = a.c9[1][0]; cc_ = a.c9[1][1]; ce_ = a.c9[1][2];
     csw = a.c9[2][0]; cs_ = a.c9[2][1]; cse = a.c9[2][2];
-    rw = a.c9row[0]; rc = a.c9row[1]; re = a.c9row[2];
-    kn = a.c9col[0]; kc = a.c9col[1]; ks = a.c9col[2];
-    kcr = a.c9corner;
+    // stored as differences to the interior values so that a row / column flag blends them in
+    rw = a.c9row[0] - cw_; rc = a.c9row[1] - cc_; re = a.c9row[2] - ce_;
+    kn = a.c9col[0] - cn_; kc = a.c9col[1] - cc_; ks = a.c9col[2] - cs_;
+    kcr = a.c9corner - a.c9row[1] - a.c9col[1] + cc_;
     mu = a.shifts[q];
-    last_col_b = ja + 1 == nc - 1;
+    lastb = (ja + 1 == nc - 1) ? 1.0 : 0.0;
     last_row_index = a.last_row;
-    last_row = false;
-    w_ = cw_; c_ = cc_; e_ = ce_;
+    lr = 0.0;
+    // reciprocals of the four possible diagonals (interior, last row, last column, corner), as blends
+    i00 = 1.0 / (cc_ - mu);
+    const double i10 = 1.0 / (a.c9row[1] - mu), i01 = 1.0 / (a.c9col[1] - mu), i11 = 1.0 / (a.c9corner - mu);
+    ir = i10 - i00;
+    ic = i01 - i00;
+    irc = i11 - i10 - i01 + i00;
   }
-  __device__ __forceinline__ void set_row(const FusedArgs&, long row) {
-    last_row = row == last_row_index;
-    w_ = last_row ? rw : cw_;
-    c_ = last_row ? rc : cc_;
-    e_ = last_row ? re : ce_;
-  }
+  __device__ __forceinline__ void set_row(const FusedArgs&, long row) { lr = row == last_row_index ? 1.0 : 0.0; }
   template <int COL>
   __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
-    double vn = cn_, vc = c_, vs = cs_;
-    if (COL == 1 && last_col_b) {  // ja+1 is the last column: centre-column coefficients change
-      vn = kn;
-      vs = ks;
-      vc = last_row ? kcr : kc;
-    }
-    off = cnw * n[0] + vn * n[1] + cne * n[2] + w_ * c[0] + e_ * c[2] + csw * s[0] + vs * s[1] + cse * s[2];
+    const double lc = COL == 1 ? lastb : 0.0;
+    const double w = cw_ + lr * rw, e = ce_ + lr * re;
+    const double vn = cn_ + lc * kn, vs = cs_ + lc * ks;
+    const double vc = cc_ + lr * rc + lc * kc + (lr * lc) * kcr;
+    off = cnw * n[0] + vn * n[1] + cne * n[2] + w * c[0] + e * c[2] + csw * s[0] + vs * s[1] + cse * s[2];
     dg = vc - mu;
-    inv = 1.0 / dg;
+    inv = i00 + lr * ir + lc * ic + (lr * lc) * irc;
   }
 };
 
