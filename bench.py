@@ -47,7 +47,20 @@ def cpu_baseline(args, kind_name):
         from oracle import structured
     except Exception as e:                                     # oracle not built: report, do not fail the bench
         return {"value": None, "unit": "MLUPS", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
-    return structured.time_cpu_baseline(kind_name, args.nu, args.lowest, args.cpu_seconds)
+    return structured.time_cpu_baseline(kind_name, args.nu, args.lowest, args.cpu_seconds, grid=min(args.grid, 8192),
+                                        workload_grid=args.grid)
+
+
+def measured_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of scripts/gpu_pmc.sh (rocprofv3 cannot
+    profile the process it runs in; the summary of that run of this same command is kept under profiles/)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            table = json.load(fh)
+        return table.get("%s_%d" % (args.smoother, args.grid))
+    except Exception:
+        return None
 
 
 def main():
@@ -91,10 +104,18 @@ def main():
     sweeps = 2 * args.nu
     value = n * sweeps * args.steps / elapsed / 1e6
     # dominant kernel: the fine-level smoother sweep, timed alone with HIP events on the same stream
+    # (one launch = one fused pass of up to 2 sweeps: algorithmic bytes per launch = 24 B x points x sweeps in it)
     reps = 10
+    fuse = plan.fused_max_sweeps(0, kind)
+    launches = -(-args.nu // fuse) if fuse else args.nu * (1 if kind == _lib.WJACOBI else 4)
     ms = plan.time_smoother(0, kind, args.nu, omega, reps)
+    launch_s = ms * 1e-3 / (reps * launches)
     sweep_s = ms * 1e-3 / (reps * args.nu)
     achieved = n * BYTES_PER_LUP / sweep_s / 1e9
+    ms1 = plan.time_smoother(0, kind, 1, omega, reps)              # one sweep per launch: the unfused comparison
+    achieved1 = n * BYTES_PER_LUP / (ms1 * 1e-3 / reps) / 1e9
+    probe = {name: n * bpp / (plan.bandwidth_probe(0, k_, 1024, 5) * 1e-3) / 1e9
+             for k_, name, bpp in ((0, "copy", 16), (1, "triad", 24), (2, "read", 8))}
     out = {
         "metric": "fine_grid_mlups_vcycle_2d_laplacian_fp64",
         "value": value,
@@ -114,11 +135,15 @@ def main():
                    "grid": g, "smoother": args.smoother, "nu1": args.nu, "nu2": args.nu, "lowest_level": args.lowest},
         "vcycles_per_s": args.steps / elapsed,
         "smoother_mlups": n / sweep_s / 1e6,
-        "roofline": {"bound": "hbm", "kernel": "fine-level %s sweep" % args.smoother, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": n * BYTES_PER_LUP, "avg_launch_ms": sweep_s * 1e3},
+        "roofline": {"bound": "hbm", "kernel": "fused fine-level pass (%d %s sweep(s) per launch)" % (args.nu // launches, args.smoother),
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": n * BYTES_PER_LUP * args.nu / launches, "avg_launch_ms": launch_s * 1e3,
+                     "fusion_depth": args.nu / launches,
+                     "single_sweep_per_launch": {"achieved": achieved1, "frac": achieved1 / HBM_PEAK_GBS},
+                     "measured_ceilings_GBs": probe},
         "device": _lib.device_name(0),
     }
+    out["roofline"]["traffic"] = measured_traffic(args)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.smoother)
     print(json.dumps(out))

@@ -102,6 +102,8 @@ int mgcmt_set_shifts(mgcmt_plan* plan, const double* shifts, int k, void* stream
 int mgcmt_upload(mgcmt_plan* plan, int level, int slot, int vec, const double* host, int64_t count, void* stream);
 int mgcmt_download(mgcmt_plan* plan, int level, int slot, int vec, double* host, int64_t count, void* stream);
 int mgcmt_fill(mgcmt_plan* plan, int level, int slot, int vec, double value, void* stream);
+/* vector := 0 including its halo rows (a sharded cycle restarts the coarse iterate without an exchange) */
+int mgcmt_zero(mgcmt_plan* plan, int level, int slot, int vec, void* stream);
 int mgcmt_copy(mgcmt_plan* plan, int level, int src_slot, int src_vec, int dst_slot, int dst_vec, void* stream);
 int mgcmt_sync(void* stream);
 
@@ -137,6 +139,15 @@ int mgcmt_scale(mgcmt_plan* plan, int level, double alpha, int slot, int vec, vo
 int mgcmt_gramschmidt(mgcmt_plan* plan, int level, int slot, int k, int modified, void* stream);
 /* columns scaled to unit 2-norm (normalize, :52-63) */
 int mgcmt_normalize(mgcmt_plan* plan, int level, int slot, int k, void* stream);
+
+/* Building blocks of a sharded cycle (multigridcmt_amd/distributed.py exchanges halo rows between them).
+ * mgcmt_fused_pass: ONE fused row-streaming pass on `level`, V <- nsweep sweeps of `kind` (MGCMT_WJACOBI or
+ * MGCMT_GS_MC) applied to V, optionally preceded by V += P V[level+1] (mode 1, MGCMTSolver.py:323-324) or
+ * followed by F[level+1] <- R (F - (A - mu I) V) (mode 2, :315).  The pass reads MGCMT_HALO_ROWS halo rows of V
+ * and F (and of V[level+1] in mode 1) around a strip.  mgcmt_fused_max_sweeps: sweeps one pass can take on that
+ * level (0 = the level is not covered by the fused kernels). */
+int mgcmt_fused_pass(mgcmt_plan* plan, int level, int kind, int nsweep, double omega, int mode, int k, void* stream);
+int mgcmt_fused_max_sweeps(const mgcmt_plan* plan, int level, int kind, int* max_sweeps);
 
 /* plan options: MGCMT_OPT_FUSED (default 1) selects the fused row-streaming kernels on large constant-
  * coefficient levels; 0 forces the one-launch-per-operation kernels everywhere (A/B checks) */

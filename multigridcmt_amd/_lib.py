@@ -53,6 +53,7 @@ _SIGNATURES = {
     "mgcmt_upload": (c_int, [c_void_p, c_int, c_int, c_int, _dp, c_int64, c_void_p]),
     "mgcmt_download": (c_int, [c_void_p, c_int, c_int, c_int, _dp, c_int64, c_void_p]),
     "mgcmt_fill": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p]),
+    "mgcmt_zero": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "mgcmt_copy": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mgcmt_sync": (c_int, [c_void_p]),
     "mgcmt_smooth": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p]),
@@ -69,6 +70,8 @@ _SIGNATURES = {
     "mgcmt_scale": (c_int, [c_void_p, c_int, c_double, c_int, c_int, c_void_p]),
     "mgcmt_gramschmidt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mgcmt_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mgcmt_fused_pass": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p]),
+    "mgcmt_fused_max_sweeps": (c_int, [c_void_p, c_int, c_int, POINTER(c_int)]),
     "mgcmt_plan_set_option": (c_int, [c_void_p, c_int, c_int]),
     "mgcmt_bandwidth_probe": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _dp, c_void_p]),
     "mgcmt_time_smoother": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, _dp, c_void_p]),

@@ -709,6 +709,14 @@ int mgcmt_fill(mgcmt_plan* p, int l, int slot, int vec, double value, void* stre
   return post_launch();
 }
 
+int mgcmt_zero(mgcmt_plan* p, int l, int slot, int vec, void* stream) {
+  MG_TRY(check_vec(p, l, slot, vec));
+  MG_TRY(ensure_slot(p, l, slot));
+  const Level& L = p->levels[l];
+  MG_HIP(hipMemsetAsync(p->kvec(l, slot, vec).p - (long)kHalo * L.gc, 0, sizeof(double) * (size_t)(L.nr + 2 * kHalo) * L.gc, S(stream)));
+  return MGCMT_OK;
+}
+
 int mgcmt_copy(mgcmt_plan* p, int l, int src_slot, int src_vec, int dst_slot, int dst_vec, void* stream) {
   MG_TRY(check_vec(p, l, src_slot, src_vec));
   MG_TRY(check_vec(p, l, dst_slot, dst_vec));
@@ -851,6 +859,30 @@ int mgcmt_normalize(mgcmt_plan* p, int l, int slot, int k, void* stream) {
     launch_scale_dev(S(stream), p->interior(l), p->d_scalars, 1, a);
   }
   return post_launch();
+}
+
+int mgcmt_fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, void* stream) {
+  MG_TRY(check_level(p, l));
+  MG_TRY(check_k(p, k));
+  if (!fused_level(p, l, kind)) return fail(MGCMT_ERR_UNSUPPORTED, "level / smoother not covered by the fused kernels");
+  if (nsweep < 1 || nsweep > pass_sweeps(p, l, kind, nsweep) || mode < 0 || mode > 2) return fail(MGCMT_ERR_INVALID, "bad nsweep or mode");
+  if (mode != 0 && l + 1 >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "no coarser level");
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
+  if (mode != 0) {
+    MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
+    MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_F));
+  }
+  MG_TRY(fused_pass(p, l, kind, nsweep, omega, mode, k, S(stream)));
+  return post_launch();
+}
+
+int mgcmt_fused_max_sweeps(const mgcmt_plan* p, int l, int kind, int* max_sweeps) {
+  MG_TRY(check_level(p, l));
+  if (!max_sweeps) return fail(MGCMT_ERR_INVALID, "null output");
+  *max_sweeps = fused_level(p, l, kind) ? pass_sweeps(p, l, kind, 1 << 20) : 0;
+  return MGCMT_OK;
 }
 
 int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {

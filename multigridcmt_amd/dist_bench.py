@@ -1,0 +1,75 @@
+"""bench.py's multi-GPU leg: one process per GPU (torch.distributed, backend nccl = RCCL), strong scaling on a
+fixed grid.  Rank 0 prints the JSON line; time is the maximum over ranks between two barriers."""
+import json
+import os
+import time
+
+import numpy as np
+
+
+def run(args):
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    from .distributed import ShardedPlan
+    from .operators import laplacian_operator
+
+    rank = int(os.environ["RANK"])
+    world = int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    g = args.grid
+    kind = _lib.WJACOBI if args.smoother == "wjacobi" else _lib.GS_MC
+    omega = 2.0 / 3.0 if args.smoother == "wjacobi" else 1.0
+    op = laplacian_operator(g, "2d") * (-1.0 / np.pi ** 2)
+    sp = ShardedPlan(op, args.lowest, rank, world, device=local)
+    sp.set_shift(0.0)
+    rows = g // world
+    f = np.random.RandomState(1 + rank).rand(rows * g)
+    sp.upload_local(_lib.SLOT_F, f)
+    sp.plan.fill(0, _lib.SLOT_V, 0, 0.0)
+    del f
+
+    def cycle():
+        sp.vcycle(args.nu, args.nu, kind, omega=omega, nu_coarse=args.nu)
+
+    for _ in range(args.warmup):
+        cycle()
+    sp.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cycle()
+    sp.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda:%d" % local)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    n = float(g) * g
+    if rank == 0:
+        out = {
+            "metric": "fine_grid_mlups_vcycle_2d_laplacian_fp64",
+            "value": n * 2 * args.nu * args.steps / elapsed / 1e6,
+            "unit": "MLUPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "2D Laplacian %d^2 fp64, V(%d,%d) %s, lowest_level %d, %dxMI355X row strips down to %d^2, "
+                                   "RCCL halo exchange" % (g, args.nu, args.nu, args.smoother, args.lowest, world, sp.switch),
+                       "grid": g, "smoother": args.smoother, "nu1": args.nu, "nu2": args.nu, "lowest_level": args.lowest,
+                       "parallelism": "strips%d" % world, "strip_levels": sp.strip_levels},
+            "vcycles_per_s": args.steps / elapsed,
+        }
+        print(json.dumps(out), flush=True)
+    sp.close()
+    dist.destroy_process_group()

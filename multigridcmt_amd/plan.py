@@ -103,6 +103,9 @@ class Plan:
     def fill(self, level, slot, vec, value, stream=None):
         check(_lib.lib().mgcmt_fill(self._h, level, slot, vec, c_double(value), stream))
 
+    def zero(self, level, slot, vec, stream=None):
+        check(_lib.lib().mgcmt_zero(self._h, level, slot, vec, stream))
+
     def copy(self, level, src_slot, src_vec, dst_slot, dst_vec, stream=None):
         check(_lib.lib().mgcmt_copy(self._h, level, src_slot, src_vec, dst_slot, dst_vec, stream))
 
@@ -154,6 +157,14 @@ class Plan:
 
     def normalize(self, level, slot, k, stream=None):
         check(_lib.lib().mgcmt_normalize(self._h, level, slot, k, stream))
+
+    def fused_pass(self, level, kind, nsweep, omega=1.0, mode=0, k=1, stream=None):
+        check(_lib.lib().mgcmt_fused_pass(self._h, level, kind, nsweep, c_double(omega), mode, k, stream))
+
+    def fused_max_sweeps(self, level, kind):
+        n = c_int(0)
+        check(_lib.lib().mgcmt_fused_max_sweeps(self._h, level, kind, ctypes.byref(n)))
+        return n.value
 
     def set_option(self, option, value):
         check(_lib.lib().mgcmt_plan_set_option(self._h, option, int(value)))

@@ -129,7 +129,7 @@ def vcycle(X, Y, g, lowest, shift, kind, v0, f, nu1=4, nu2=4, nu_coarse=4, omega
     return v
 
 
-def time_cpu_baseline(smoother, nu, lowest, budget_seconds, grid=8192):
+def time_cpu_baseline(smoother, nu, lowest, budget_seconds, grid=8192, workload_grid=None):
     """bench.py's cpu_baseline: whole V(nu,nu) cycles of the same workload on the host cores (OpenMP over
     all of them for the order-independent sweeps), for about budget_seconds."""
     kind, omega = (WJACOBI, 2. / 3.) if smoother == "wjacobi" else (GS_MC, 1.0)
@@ -150,6 +150,7 @@ def time_cpu_baseline(smoother, nu, lowest, budget_seconds, grid=8192):
         cycles += 1
     mlups = float(g) * g * 2 * nu * cycles / spent / 1e6
     return {"value": mlups, "unit": "MLUPS", "cores": threads, "kind": "port",
-            "sample": "%d V(%d,%d) %s cycles on the same %d^2 grid after 1 warm-up cycle, C restatement (oracle/mgcmt_oracle.c), "
-                      "OpenMP x%d" % (cycles, nu, nu, smoother, g, threads),
+            "sample": "%d whole V(%d,%d) %s cycles on a %d^2 grid (bounded sample of the %s^2 workload; MLUPS is per point) after "
+                      "1 warm-up cycle, C restatement oracle/mgcmt_oracle.c, OpenMP x%d" %
+                      (cycles, nu, nu, smoother, g, workload_grid or g, threads),
             "vcycles_per_s": cycles / spent}

@@ -1,0 +1,82 @@
+"""The sharded V-cycle (multigridcmt_amd/distributed.py) with world_size 2 and 4 on CPU: gloo for the halo
+exchange, the emulated kernels for the compute.  The sharded result must equal the single-plan result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_err
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, g, kind, omega, nu, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hip_cpu_mock")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import build_emu
+    from multigridcmt_amd import _lib
+    _lib.use_library(build_emu.build())
+    from multigridcmt_amd.distributed import ShardedPlan
+    from multigridcmt_amd.operators import laplacian_operator
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    op = laplacian_operator(g, "2d") * (-1 / np.pi ** 2)
+    sp = ShardedPlan(op, 8, rank, world, switch_grid=g // 4, on_gpu=False)
+    sp.set_shift(0.4)
+    rng = np.random.RandomState(5)
+    f, v0 = rng.rand(g * g), rng.rand(g * g)
+    rows = g // world
+    sl = slice(rank * rows * g, (rank + 1) * rows * g)
+    sp.upload_local(_lib.SLOT_F, f[sl])
+    sp.upload_local(_lib.SLOT_V, v0[sl])
+    for _ in range(2):
+        sp.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu)
+    res = sp.residual_norm()
+    np.save(os.path.join(out_dir, "part%d.npy" % rank), sp.download_local(_lib.SLOT_V))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "res.npy"), np.array([res, sp.strip_levels]))
+    sp.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("kind_name", ["wjacobi", "rb"])
+def test_sharded_cycle_equals_single_plan(tmp_path, world, kind_name):
+    import torch.multiprocessing as mp
+    from conftest import bind_backend
+    bind_backend("emu")
+    from multigridcmt_amd import _lib
+    from multigridcmt_amd.operators import laplacian_operator
+    from multigridcmt_amd.plan import Plan
+    g, nu = 1024, 2
+    kind, omega = (_lib.WJACOBI, 2. / 3.) if kind_name == "wjacobi" else (_lib.GS_MC, 1.0)
+    mp.spawn(_worker, args=(world, _free_port(), g, kind, omega, nu, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("part%d.npy" % r)) for r in range(world)])
+    res, strip_levels = np.load(tmp_path / "res.npy")
+    assert strip_levels == 2
+    p = Plan(laplacian_operator(g, "2d") * (-1 / np.pi ** 2), 8, nvec=1)
+    p.set_shifts([0.4])
+    rng = np.random.RandomState(5)
+    f, v0 = rng.rand(g * g), rng.rand(g * g)
+    p.upload(0, _lib.SLOT_F, 0, f)
+    p.upload(0, _lib.SLOT_V, 0, v0)
+    for _ in range(2):
+        p.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu)
+    want = p.download(0, _lib.SLOT_V, 0)
+    p.apply(0, (_lib.SLOT_V, 0), (_lib.SLOT_T, 0), with_shift=True)
+    p.axpy(0, -1.0, (_lib.SLOT_F, 0), (_lib.SLOT_T, 0))
+    want_res = np.sqrt(p.dot(0, (_lib.SLOT_T, 0), (_lib.SLOT_T, 0)))
+    p.close()
+    assert rel_err(got, want) < 1e-12
+    assert abs(res - want_res) < 1e-9 * want_res
