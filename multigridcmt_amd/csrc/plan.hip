@@ -518,7 +518,7 @@ int mgcmt_device_name(int device, char* buf, int buflen) {
   if (!buf || buflen <= 0) return fail(MGCMT_ERR_INVALID, "bad buffer");
   hipDeviceProp_t prop;
   MG_HIP(hipGetDeviceProperties(&prop, device));
-  snprintf(buf, buflen, "%s (%s)", prop.name, prop.gcnArchName);
+  snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName, prop.multiProcessorCount);
   return MGCMT_OK;
 }
 

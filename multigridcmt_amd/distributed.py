@@ -38,6 +38,10 @@ class ShardedPlan:
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        if on_gpu and not torch.cuda.is_available():
+            raise _lib.MgcmtError(
+                "PyTorch sees no GPU.  In a process that uses both, import torch BEFORE the first call into "
+                "libmgcmt_hip.so: each brings a HIP runtime and only the first one loaded can open the device.")
         self.rank, self.world, self.on_gpu = rank, world, on_gpu
         self.device = device
         if op.dimension != "2d":

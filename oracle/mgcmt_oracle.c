@@ -36,6 +36,14 @@ typedef struct {
   double c0, cn, cw;
 } mgo_level;
 
+void mgo_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int mgo_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -133,6 +133,8 @@ def time_cpu_baseline(smoother, nu, lowest, budget_seconds, grid=8192, workload_
     """bench.py's cpu_baseline: whole V(nu,nu) cycles of the same workload on the host cores (OpenMP over
     all of them for the order-independent sweeps), for about budget_seconds."""
     kind, omega = (WJACOBI, 2. / 3.) if smoother == "wjacobi" else (GS_MC, 1.0)
+    # a one-GPU box's CPU share is 16 cores (more threads than that only thrash one NUMA node)
+    lib().mgo_set_threads(min(os.cpu_count() or 1, 16))
     threads = lib().mgo_threads()
     g = grid
     X, Y = laplacian_factors(g, "2d", scale=-1.0 / np.pi ** 2)
