@@ -143,7 +143,8 @@ int mgcmt_normalize(mgcmt_plan* plan, int level, int slot, int k, void* stream);
 /* Building blocks of a sharded cycle (multigridcmt_amd/distributed.py exchanges halo rows between them).
  * mgcmt_fused_pass: ONE fused row-streaming pass on `level`, V <- nsweep sweeps of `kind` (MGCMT_WJACOBI or
  * MGCMT_GS_MC) applied to V, optionally preceded by V += P V[level+1] (mode 1, MGCMTSolver.py:323-324) or
- * followed by F[level+1] <- R (F - (A - mu I) V) (mode 2, :315).  The pass reads MGCMT_HALO_ROWS halo rows of V
+ * followed by F[level+1] <- R (F - (A - mu I) V) (mode 2, :315); adding 4 to mode 0 or 2 declares the incoming V
+ * to be zero (it is then neither read nor required to have been cleared, :316).  The pass reads MGCMT_HALO_ROWS halo rows of V
  * and F (and of V[level+1] in mode 1) around a strip.  mgcmt_fused_max_sweeps: sweeps one pass can take on that
  * level (0 = the level is not covered by the fused kernels). */
 int mgcmt_fused_pass(mgcmt_plan* plan, int level, int kind, int nsweep, double omega, int mode, int k, void* stream);

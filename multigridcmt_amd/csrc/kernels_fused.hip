@@ -38,7 +38,10 @@ namespace {
 #endif
 constexpr int kDepth = MGCMT_FUSED_DEPTH;         // rows per prefetch batch (two batches of registers)
 constexpr int kWavesPerBlock = MGCMT_FUSED_WAVES;
-constexpr int kDepth9 = 2;  // 9-point policies carry wider windows: shallower batches keep two or three waves per SIMD
+#ifndef MGCMT_FUSED_DEPTH9
+#define MGCMT_FUSED_DEPTH9 2
+#endif
+constexpr int kDepth9 = MGCMT_FUSED_DEPTH9;  // 9-point policies carry wider windows: shallower batches keep two or three waves per SIMD
 
 struct FusedArgs {
   const double* vin;
@@ -222,7 +225,9 @@ struct FusedShape {
   static constexpr int wout = 128 - 2 * halo;                                     // columns a wave produces
 };
 
-template <class OP, int KIND, int NSWEEP, bool PROLONG, bool RESTRICT>
+// ZERO_IN: the incoming iterate is identically zero (the error equation on a coarser level starts from
+// zero, MGCMTSolver.py:316): V is not read at all and nobody has to clear it first.
+template <class OP, int KIND, int NSWEEP, bool PROLONG, bool RESTRICT, bool ZERO_IN>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   using Shape = FusedShape<OP, KIND, NSWEEP, PROLONG, RESTRICT>;
   constexpr int S = Shape::S, E = Shape::E, HALO = Shape::halo, WOUT = Shape::wout;
@@ -282,7 +287,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   Row setA[D], setB[D];
   auto fetch = [&](long row, Row& r) __attribute__((always_inline)) {
     const long rl = row < a.row_lo ? a.row_lo : (row >= a.row_hi ? a.row_hi - 1 : row);
-    r.v = load2(vin + rl * nc + ja_ld);
+    if (ZERO_IN) r.v = make_double2(0.0, 0.0);
+    else r.v = load2(vin + rl * nc + ja_ld);
     r.f = load2_stream(fin + rl * nc + ja_ld);
     r.e = 0.0;
     if (PROLONG) {
@@ -467,7 +473,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
 
 long g_fused_rows_override = MGCMT_FUSED_ROWS;  // 0 = automatic
 
-template <class OP, int KIND, int NSWEEP, bool PROLONG, bool RESTRICT>
+template <class OP, int KIND, int NSWEEP, bool PROLONG, bool RESTRICT, bool ZERO_IN>
 void launch_one(hipStream_t s, FusedArgs a, int k) {
   using Shape = FusedShape<OP, KIND, NSWEEP, PROLONG, RESTRICT>;
   const long strips = (a.nc + Shape::wout - 1) / Shape::wout;
@@ -483,7 +489,7 @@ void launch_one(hipStream_t s, FusedArgs a, int k) {
   if (resident_blocks == 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<OP, KIND, NSWEEP, PROLONG, RESTRICT>, 64 * kWavesPerBlock, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<OP, KIND, NSWEEP, PROLONG, RESTRICT, ZERO_IN>, 64 * kWavesPerBlock, 0) != hipSuccess ||
         hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
       resident_blocks = 768;
     else
@@ -501,14 +507,21 @@ void launch_one(hipStream_t s, FusedArgs a, int k) {
   a.rows_per_chunk = (int)rows;
   a.n_row_chunks = (int)((a.nr + rows - 1) / rows);
   const unsigned blocks = (unsigned)(groups8 * a.n_row_chunks);
-  hipLaunchKernelGGL((k_fused<OP, KIND, NSWEEP, PROLONG, RESTRICT>), dim3(blocks, (unsigned)k), dim3(64 * kWavesPerBlock), 0, s, a);
+  hipLaunchKernelGGL((k_fused<OP, KIND, NSWEEP, PROLONG, RESTRICT, ZERO_IN>), dim3(blocks, (unsigned)k), dim3(64 * kWavesPerBlock), 0, s, a);
 }
 
 template <class OP, int KIND, int NSWEEP>
 void launch_mode(hipStream_t s, const FusedArgs& a, int mode, int k) {
-  if (mode == 1) launch_one<OP, KIND, NSWEEP, true, false>(s, a, k);
-  else if (mode == 2) launch_one<OP, KIND, NSWEEP, false, true>(s, a, k);
-  else launch_one<OP, KIND, NSWEEP, false, false>(s, a, k);
+  const bool zero_in = (mode & 4) != 0;
+  mode &= 3;
+  if (mode == 1) launch_one<OP, KIND, NSWEEP, true, false, false>(s, a, k);
+  else if (mode == 2) {
+    if (zero_in) launch_one<OP, KIND, NSWEEP, false, true, true>(s, a, k);
+    else launch_one<OP, KIND, NSWEEP, false, true, false>(s, a, k);
+  } else {
+    if (zero_in) launch_one<OP, KIND, NSWEEP, false, false, true>(s, a, k);
+    else launch_one<OP, KIND, NSWEEP, false, false, false>(s, a, k);
+  }
 }
 
 }  // namespace
@@ -524,16 +537,16 @@ bool fused_supported(const KGrid& g, const KOp& op) {
 // sweeps one pass can fuse: a 9-point four-colour sweep is already four pipeline stages
 int fused_max_sweeps(const KOp& op, int multicolour) { return (!op.five_point && multicolour) ? 1 : 2; }
 
-// One fused pass: vin -> vout with `nsweep` sweeps; mode 0 plain, 1 prolong+correct first (coarse
-// correction `coarse`), 2 residual+restriction last (coarse right-hand side `coarse`).
+// One fused pass: vin -> vout with `nsweep` sweeps; mode & 3: 0 plain, 1 prolong+correct first (coarse
+// correction `coarse`), 2 residual+restriction last (coarse right-hand side `coarse`); mode & 4: vin is zero.
 void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
                   double omega, int multicolour, int nsweep, int mode, long row_lo, long row_hi, long last_row, int k) {
   FusedArgs a{};
   a.vin = vin.p;
   a.f = f.p;
   a.vout = vout.p;
-  a.ec = mode == 1 ? coarse.p : nullptr;
-  a.rc = mode == 2 ? coarse.p : nullptr;
+  a.ec = (mode & 3) == 1 ? coarse.p : nullptr;
+  a.rc = (mode & 3) == 2 ? coarse.p : nullptr;
   a.nr = g.nr;
   a.nc = g.nc;
   a.row_lo = row_lo;

@@ -285,8 +285,8 @@ int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mod
   Level& L = p->levels[l];
   KVec coarse{nullptr, 0};
   long cnc = 0;
-  if (mode != 0) {
-    coarse = p->kvec(l + 1, mode == 1 ? MGCMT_SLOT_V : MGCMT_SLOT_F);
+  if ((mode & 3) != 0) {
+    coarse = p->kvec(l + 1, (mode & 3) == 1 ? MGCMT_SLOT_V : MGCMT_SLOT_F);
     cnc = p->levels[l + 1].gc;
   }
   const long row_lo = L.r0 == 0 ? 0 : -kHalo;
@@ -415,25 +415,36 @@ int coarse_solve_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
 }
 
 // pre-smoothing + residual + restriction (MGCMTSolver.py:313-316); one pass less on fused levels
-int down_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hipStream_t s) {
+// zero_in: V[l] is known to be zero (and has not been cleared); true below the level the cycle starts on
+int down_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, bool zero_in, hipStream_t s) {
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
+  MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_F));
+  // a fused first pass takes "V is zero" as a flag; the one-launch-per-operation path needs V cleared
+  if (zero_in && !(nu >= 1 && fused_level(p, l, kind)))
+    for (int q = 0; q < k; ++q) launch_fill(s, p->kvec(l, MGCMT_SLOT_V, q).p, p->interior(l), 0.0);
   if (nu >= 1 && fused_level(p, l, kind)) {
     MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
     MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
     MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
     MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
     MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_F));
-    int left = nu;
+    int left = nu, zi = zero_in ? 4 : 0;
     while (left > pass_sweeps(p, l, kind, left)) {
       const int n = pass_sweeps(p, l, kind, left);
-      MG_TRY(fused_pass(p, l, kind, n, omega, 0, k, s));
+      MG_TRY(fused_pass(p, l, kind, n, omega, zi, k, s));
+      zi = 0;
       left -= n;
     }
-    MG_TRY(fused_pass(p, l, kind, left, omega, 2, k, s));
-    for (int q = 0; q < k; ++q) launch_fill(s, p->kvec(l + 1, MGCMT_SLOT_V, q).p, p->interior(l + 1), 0.0);
+    MG_TRY(fused_pass(p, l, kind, left, omega, 2 | zi, k, s));
     return post_launch();
   }
   MG_TRY(smooth_impl(p, l, kind, nu, omega, k, s));
-  return residual_restrict_impl(p, l, k, s);
+  launch_residual(s, p->kgrid(l), p->levels[l].dA.k, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_T), p->d_shifts, k);
+  launch_restrict(s, p->kgrid(l), p->kgrid(l + 1), p->kvec(l, MGCMT_SLOT_T), p->kvec(l + 1, MGCMT_SLOT_F), k);
+  return post_launch();
 }
 
 // prolongation + correction + post-smoothing (MGCMTSolver.py:323-326)
@@ -763,7 +774,7 @@ int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int 
   MG_TRY(check_k(p, k));
   const int last = (int)p->levels.size() - 1;
   hipStream_t s = S(stream);
-  for (int l = level; l < last; ++l) MG_TRY(down_leg(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, s));
+  for (int l = level; l < last; ++l) MG_TRY(down_leg(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, l > level, s));
   MG_TRY(coarse_solve_impl(p, last, k, s));
   for (int l = last - 1; l >= level; --l) {
     MG_TRY(up_leg(p, l, kind, l == level ? nu2 : nu_coarse, omega, k, s));
@@ -777,7 +788,7 @@ int mgcmt_twogrid(mgcmt_plan* p, int level, int nu1, int nu2, int kind, double o
   MG_TRY(check_k(p, k));
   if (level + 1 >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "twogrid needs a coarser level");
   hipStream_t s = S(stream);
-  MG_TRY(down_leg(p, level, kind, nu1, omega, k, s));
+  MG_TRY(down_leg(p, level, kind, nu1, omega, k, false, s));
   MG_TRY(coarse_solve_impl(p, level + 1, k, s));
   MG_TRY(up_leg(p, level, kind, nu2, omega, k, s));
   return MGCMT_OK;
@@ -865,12 +876,13 @@ int mgcmt_fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, i
   MG_TRY(check_level(p, l));
   MG_TRY(check_k(p, k));
   if (!fused_level(p, l, kind)) return fail(MGCMT_ERR_UNSUPPORTED, "level / smoother not covered by the fused kernels");
-  if (nsweep < 1 || nsweep > pass_sweeps(p, l, kind, nsweep) || mode < 0 || mode > 2) return fail(MGCMT_ERR_INVALID, "bad nsweep or mode");
-  if (mode != 0 && l + 1 >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "no coarser level");
+  if (nsweep < 1 || nsweep > pass_sweeps(p, l, kind, nsweep) || mode < 0 || mode > 6 || (mode & 3) == 3 || mode == 5)
+    return fail(MGCMT_ERR_INVALID, "bad nsweep or mode");
+  if ((mode & 3) != 0 && l + 1 >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "no coarser level");
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
-  if (mode != 0) {
+  if ((mode & 3) != 0) {
     MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
     MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_F));
   }

@@ -206,11 +206,11 @@ class ShardedPlan:
                         self.exchange_halo((0, SLOT_V), (0, SLOT_F))
                         self._fine_rhs_halo_valid = True
                 elif i == 0:
-                    self.exchange_halo((l, SLOT_F))        # V[l] starts at zero, halo rows included
+                    self.exchange_halo((l, SLOT_F))        # V[l] starts at zero: nothing to exchange, nothing to read
                 else:
                     self.exchange_halo((l, SLOT_V))
-                P.fused_pass(l, kind, n, omega=omega, mode=2 if i == len(passes) - 1 else 0)
-            P.zero(l + 1, SLOT_V, 0)
+                mode = (2 if i == len(passes) - 1 else 0) | (4 if (i == 0 and l > 0) else 0)
+                P.fused_pass(l, kind, n, omega=omega, mode=mode)
         # the coarse problem: gather, run the sub-cycle on rank 0, scatter the correction with its halo rows
         self.gather_to_root(ls, SLOT_F, SLOT_F)
         if self.rank == 0:

@@ -3,7 +3,6 @@ set -e
 cd "$(dirname "$0")/../multigridcmt_amd/csrc"
 rm -rf ../../build/variants; mkdir -p ../../build/variants
 build() { name=$1; shift; make -s -j8 OUT=$PWD/../../build/variants/lib_$name.so OBJDIR=$PWD/../../build/variants/obj_$name EXTRA="$*"; echo built $name; }
-build nts -DMGCMT_FUSED_NT_STORE=1
-build ntsf -DMGCMT_FUSED_NT_STORE=1 -DMGCMT_FUSED_NT_F=1
-build d2 -DMGCMT_FUSED_DEPTH=2
-build d2nts -DMGCMT_FUSED_DEPTH=2 -DMGCMT_FUSED_NT_STORE=1
+build d9_4 -DMGCMT_FUSED_DEPTH9=4
+build d9_1 -DMGCMT_FUSED_DEPTH9=1
+build w2 -DMGCMT_FUSED_WAVES=2
