@@ -1,0 +1,90 @@
+"""Python-3 counterparts of the compute sections of the reference's driver scripts (no plotting).
+
+* ``shift_invert_eigenpairs``  — 1DPotMatrixVcycle.py:42-80 / 2DPotMatrixVcycle.py:54-109: coarse-grid Lanczos
+  guesses, interpolation to the fine grid, then ``max_iters`` rounds of  w = vcycle_matrix(0, V, H, shifts=guesses),
+  V = normalised columns of w  (shift-and-invert iteration whose linear solves are single V-cycles).
+* ``rayleigh_quotient_multigrid`` — RQMin.py:15-50: ``vcycle_rqmg`` sweeps for the lowest pair with Gram-Schmidt
+  deflation.
+
+Every V-cycle, interpolation, Gram-Schmidt and operator application runs on the GPU through MGCMTSolver /
+MGCMTProcessor; the coarse-grid ``eigsh`` stays on the host as in the reference (16 .. 256 unknowns).
+"""
+import numpy as np
+import scipy.sparse as sparse
+import scipy.sparse.linalg as sparsela
+
+from .processor import MGCMTProcessor
+from .solver import MGCMTSolver
+from .stencil_maker import MGCMTStencilMaker
+
+
+def exact_box_eigenvalues(gridsize, dimension, count):
+    """Eigenvalues of -laplacian(gridsize)/pi^2 (the discrete operator, not the continuum n^2): in 1-D
+    (4 g^2/pi^2) sin^2(k pi / (2 (g+1))), k = 1..g; in 2-D all pairwise sums, sorted."""
+    k = np.arange(1, gridsize + 1)
+    one_d = (4.0 * gridsize ** 2 / np.pi ** 2) * np.sin(k * np.pi / (2.0 * (gridsize + 1))) ** 2
+    if dimension == "1d":
+        return one_d[:count]
+    m = min(gridsize, count + 2)
+    return np.sort(np.add.outer(one_d[:m], one_d[:m]).ravel())[:count]
+
+
+def shift_invert_eigenpairs(dimension="1d", gridsize=2 ** 7, bad_gridsize=2 ** 4, num_eigenvalues=10, max_iters=10,
+                            lowest_level=None, tolerance=1e-4, guesses=None, smoother=None, verbose=False):
+    """Returns dict(eigenvalues, eigenvectors, guess_eigenvalues, history) for H = -laplacian/pi^2 on a box.
+
+    Defaults are 1DPotMatrixVcycle.py's (128 points, guesses from 16, ten pairs, ten iterations, coarsest V-cycle
+    level 16); 2DPotMatrixVcycle.py uses gridsize 64, bad_gridsize 16, max_iters 5, lowest_level 8,
+    tolerance = machine epsilon.  ``guesses`` = (values, vectors) skips the Lanczos step (ARPACK's start vector is
+    random, so fixtures store its output).
+    """
+    stencil_maker, solver = MGCMTStencilMaker(), MGCMTSolver()
+    if lowest_level is None:
+        lowest_level = 2 ** 4 if dimension == "1d" else 2 ** 3
+    hamiltonian = (-1 / np.pi ** 2) * stencil_maker.laplacian(gridsize, dimension=dimension)
+    n = hamiltonian.shape[0]
+    if guesses is None:
+        bad_hamiltonian = (-1. / np.pi ** 2) * stencil_maker.laplacian(bad_gridsize, dimension=dimension)
+        bad_eigenvalues, bad_eigenvectors = sparsela.eigsh(bad_hamiltonian, k=num_eigenvalues, which="SM", tol=tolerance)
+    else:
+        bad_eigenvalues, bad_eigenvectors = guesses
+    bad_eigenvectors = np.array(bad_eigenvectors)
+    vectors = np.zeros((n, num_eigenvalues))
+    for j in range(num_eigenvalues):
+        vectors[:, j] = solver.interpolate(bad_eigenvectors[:, j], stencil_maker, gridsize, dimension=dimension)
+        vectors[:, j] /= np.linalg.norm(vectors[:, j])
+    history = np.zeros((max_iters + 1, num_eigenvalues))
+    history[0] = [np.dot(vectors[:, j], hamiltonian.dot(vectors[:, j])) for j in range(num_eigenvalues)]
+    w0 = np.zeros((n, num_eigenvalues))
+    for it in range(1, max_iters + 1):
+        w = solver.vcycle_matrix(w0, vectors, hamiltonian, stencil_maker, shifts=bad_eigenvalues, smoother=smoother,
+                                 lowest_level=lowest_level, dimension=dimension)
+        for j in range(num_eigenvalues):
+            vectors[:, j] = w[:, j] / np.linalg.norm(w[:, j])
+            history[it, j] = np.dot(vectors[:, j], hamiltonian.dot(vectors[:, j]))
+        if verbose:
+            print(it, history[it])
+    return {"eigenvalues": history[-1].copy(), "eigenvectors": vectors, "guess_eigenvalues": np.array(bad_eigenvalues),
+            "history": history}
+
+
+def rayleigh_quotient_multigrid(gridsize=2 ** 6, first_cycles=2, second_cycles=10, seed=0):
+    """RQMin.py:15-50 for the two lowest states of -laplacian(gridsize)/pi^2 with M = I: ``first_cycles`` sweeps of
+    vcycle_rqmg on a random start, then ``second_cycles`` sweeps on a second random vector with Gram-Schmidt against
+    the first after every sweep.  Returns (rho1, rho2, X)."""
+    stencil_maker, solver, processor = MGCMTStencilMaker(), MGCMTSolver(), MGCMTProcessor()
+    A = (-1 / np.pi ** 2) * stencil_maker.laplacian(gridsize)
+    M = sparse.eye(gridsize)
+    rng = np.random.RandomState(seed)
+    x = rng.random_sample(gridsize)
+    rho = 0.0
+    for _ in range(first_cycles):
+        x, rho = solver.vcycle_rqmg(x, A, M)
+    x_matrix = np.zeros((gridsize, 2))
+    x_matrix[:, 0] = x
+    x_matrix[:, 1] = rng.random_sample(gridsize)
+    rho2 = 0.0
+    for _ in range(second_cycles):
+        x_matrix[:, 1], rho2 = solver.vcycle_rqmg(x_matrix[:, 1], A, M)
+        x_matrix = processor.gramschmidt(x_matrix)
+    return rho, rho2, x_matrix
