@@ -152,7 +152,11 @@ int mgcmt_fused_max_sweeps(const mgcmt_plan* plan, int level, int kind, int* max
 
 /* plan options: MGCMT_OPT_FUSED (default 1) selects the fused row-streaming kernels on large constant-
  * coefficient levels; 0 forces the one-launch-per-operation kernels everywhere (A/B checks) */
-typedef enum mgcmt_option { MGCMT_OPT_FUSED = 0, MGCMT_OPT_FUSED_ROWS = 1 /* tuning: rows per wave chunk, 0 = auto */ } mgcmt_option;
+typedef enum mgcmt_option {
+  MGCMT_OPT_FUSED = 0,
+  MGCMT_OPT_FUSED_ROWS = 1, /* tuning: rows per wave chunk, 0 = auto */
+  MGCMT_OPT_GRAPH = 2       /* default 1: mgcmt_vcycle replays its launch sequence as a HIP graph from the second call on */
+} mgcmt_option;
 int mgcmt_plan_set_option(mgcmt_plan* plan, int option, int value);
 
 /* timing of the dominant kernel for bench.py: runs `reps` fine-level smoother sweeps between two

@@ -131,6 +131,17 @@ struct mgcmt_plan {
   std::vector<double> h_shifts;
   bool has_mass = false;
   bool use_fused = true;
+  // HIP-graph replay of whole cycles (mgcmt_vcycle): the launch sequence of a cycle is fixed by its
+  // parameters and by which of the two buffers of every level currently is "V", so it is captured once per
+  // such state and replayed; small grids are launch-latency-bound otherwise.
+  bool use_graph = true;
+  hipStream_t capture_stream = nullptr;
+  struct CycleGraph {
+    hipGraphExec_t exec = nullptr;
+    std::vector<double*> post_state;  // base pointers of slots V and T of every level after the cycle
+  };
+  std::map<std::string, CycleGraph> graphs;
+  std::map<std::string, int> cycle_seen;
 
   KGrid kgrid(int l) const {
     KGrid kg = levels[l].grid();
@@ -507,6 +518,35 @@ int gramschmidt_impl(mgcmt_plan* p, int l, int slot, int k, int modified, hipStr
   return post_launch();
 }
 
+// (re)factor the coarsest-level matrix when the shifts changed; no-op otherwise
+int ensure_coarse_factor(mgcmt_plan* p, int l, int k, hipStream_t s) {
+  Level& L = p->levels[l];
+  BandState& B = L.band;
+  bool same = B.b.ab && B.valid && B.k >= k;
+  if (same)
+    for (int q = 0; q < k; ++q) same = same && B.shifts[q] == p->h_shifts[q];
+  if (same) return MGCMT_OK;
+  if (!B.b.ab) return MGCMT_OK;  // first use: coarse_solve_impl allocates and factors
+  launch_band_assemble(s, p->kgrid(l), L.dA.k, p->d_shifts, B.b, k);
+  launch_band_factor(s, B.b, k);
+  B.valid = true;
+  B.k = k;
+  B.shifts.assign(p->h_shifts.begin(), p->h_shifts.begin() + k);
+  return post_launch();
+}
+
+int vcycle_body(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k, int gram_schmidt,
+                hipStream_t s) {
+  const int last = (int)p->levels.size() - 1;
+  for (int l = level; l < last; ++l) MG_TRY(down_leg(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, l > level, s));
+  MG_TRY(coarse_solve_impl(p, last, k, s));
+  for (int l = last - 1; l >= level; --l) {
+    MG_TRY(up_leg(p, l, kind, l == level ? nu2 : nu_coarse, omega, k, s));
+    if (gram_schmidt) MG_TRY(gramschmidt_impl(p, l, MGCMT_SLOT_V, k, 1, s));
+  }
+  return MGCMT_OK;
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -639,6 +679,9 @@ int mgcmt_plan_destroy(mgcmt_plan* p) {
     if (L.band.b.ab) (void)hipFree(L.band.b.ab);
     if (L.band.b.piv) (void)hipFree(L.band.b.piv);
   }
+  for (auto& g : p->graphs)
+    if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+  if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
   if (p->d_shifts) (void)hipFree(p->d_shifts);
   if (p->d_zero) (void)hipFree(p->d_zero);
   if (p->d_partials) (void)hipFree(p->d_partials);
@@ -772,14 +815,65 @@ int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int 
                  void* stream) {
   MG_TRY(check_level(p, level));
   MG_TRY(check_k(p, k));
-  const int last = (int)p->levels.size() - 1;
+  if (nu1 < 0 || nu2 < 0 || nu_coarse < 0) return fail(MGCMT_ERR_INVALID, "sweep counts must be >= 0");
   hipStream_t s = S(stream);
-  for (int l = level; l < last; ++l) MG_TRY(down_leg(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, l > level, s));
-  MG_TRY(coarse_solve_impl(p, last, k, s));
-  for (int l = last - 1; l >= level; --l) {
-    MG_TRY(up_leg(p, l, kind, l == level ? nu2 : nu_coarse, omega, k, s));
-    if (gram_schmidt) MG_TRY(gramschmidt_impl(p, l, MGCMT_SLOT_V, k, 1, s));
+  if (!p->use_graph) return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt, s);
+
+  char buf[160];
+  snprintf(buf, sizeof(buf), "%d/%d/%d/%d/%d/%.17g/%d/%d", level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt);
+  const std::string params(buf);
+  std::string key = params;
+  for (const Level& L : p->levels) {
+    snprintf(buf, sizeof(buf), "|%p,%p", (void*)L.base[MGCMT_SLOT_V], (void*)L.base[MGCMT_SLOT_T]);
+    key += buf;
   }
+  auto hit = p->graphs.find(key);
+  if (hit != p->graphs.end()) {
+    // the coarsest-level factorisation depends on the shift VALUES; redo it eagerly when they changed
+    MG_TRY(ensure_coarse_factor(p, (int)p->levels.size() - 1, k, s));
+    MG_HIP(hipGraphLaunch(hit->second.exec, s));
+    size_t i = 0;
+    for (Level& L : p->levels) {
+      L.base[MGCMT_SLOT_V] = hit->second.post_state[i++];
+      L.base[MGCMT_SLOT_T] = hit->second.post_state[i++];
+    }
+    return MGCMT_OK;
+  }
+  // the first cycle with these parameters runs eagerly: it allocates, factors and queries occupancies
+  if (p->cycle_seen[params]++ == 0) return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt, s);
+  MG_TRY(ensure_coarse_factor(p, (int)p->levels.size() - 1, k, s));
+  if (!p->capture_stream && hipStreamCreate(&p->capture_stream) != hipSuccess) {
+    p->use_graph = false;
+    (void)hipGetLastError();
+    return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt, s);
+  }
+  if (hipStreamBeginCapture(p->capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    p->use_graph = false;
+    (void)hipGetLastError();
+    return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt, s);
+  }
+  const int rc = vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt, p->capture_stream);
+  hipGraph_t graph = nullptr;
+  const hipError_t end = hipStreamEndCapture(p->capture_stream, &graph);
+  if (rc != MGCMT_OK || end != hipSuccess || !graph) {
+    // nothing was executed during the capture, but the plan's buffer roles were advanced: cannot continue safely
+    p->use_graph = false;
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc != MGCMT_OK ? rc : fail(MGCMT_ERR_HIP, "graph capture of the V-cycle failed");
+  }
+  mgcmt_plan::CycleGraph cg;
+  const hipError_t inst = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (inst != hipSuccess) {
+    p->use_graph = false;
+    return fail(MGCMT_ERR_HIP, "hipGraphInstantiate failed");
+  }
+  for (const Level& L : p->levels) {
+    cg.post_state.push_back(L.base[MGCMT_SLOT_V]);
+    cg.post_state.push_back(L.base[MGCMT_SLOT_T]);
+  }
+  MG_HIP(hipGraphLaunch(cg.exec, s));
+  p->graphs[key] = cg;
   return MGCMT_OK;
 }
 
@@ -901,6 +995,10 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
   if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
   if (option == MGCMT_OPT_FUSED) {
     p->use_fused = value != 0;
+    return MGCMT_OK;
+  }
+  if (option == MGCMT_OPT_GRAPH) {
+    p->use_graph = value != 0;
     return MGCMT_OK;
   }
   if (option == MGCMT_OPT_FUSED_ROWS) {

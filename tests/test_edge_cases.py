@@ -1,0 +1,113 @@
+"""Edge cases of the boundary: zero sweeps, start grid == lowest level, many columns, strided column views,
+ragged / non-power-of-two sizes, 2-D twogrid, plan cache reuse, and the sparse oracle as the checker."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import rel_err
+from multigridcmt_amd import MGCMTProcessor, MGCMTSolver, MGCMTStencilMaker
+from oracle.sparse_ref import RefProcessor, RefSolver, RefStencilMaker
+
+S, SM = RefSolver(), RefStencilMaker()
+
+
+@pytest.fixture
+def trio(backend):
+    return MGCMTSolver(), MGCMTStencilMaker(), MGCMTProcessor()
+
+
+def H(sm, g, dim="1d"):
+    return (-1 / np.pi ** 2) * sm.laplacian(g, dimension=dim)
+
+
+def test_zero_sweeps_and_single_sweeps(trio):
+    solver, sm, _ = trio
+    rng = np.random.RandomState(0)
+    for dim, g in (("1d", 64), ("2d", 16)):
+        A = H(sm, g, dim)
+        n = A.shape[0]
+        f, v0 = rng.rand(n), rng.rand(n)
+        for nu1, nu2 in ((0, 0), (1, 0), (0, 1), (1, 1), (5, 3)):
+            x = solver.vcycle(v0.copy(), f.copy(), A, sm, nu1=nu1, nu2=nu2, shift=0.3, dimension=dim, lowest_level=4)
+            y = S.vcycle(v0, f, A, SM, nu1=nu1, nu2=nu2, shift=0.3, dimension=dim, lowest_level=4)
+            assert rel_err(x, y) < 1e-11, (dim, nu1, nu2)
+        assert rel_err(solver.wjacobi(v0.copy(), f.copy(), A, nu=0).ravel(), v0) == 0.0
+
+
+def test_start_grid_is_lowest_level(trio):
+    solver, sm, _ = trio
+    for dim, g in (("1d", 32), ("2d", 8)):
+        A = H(sm, g, dim)
+        n = A.shape[0]
+        f = np.random.RandomState(1).rand(n)
+        x = solver.vcycle(np.zeros(n), f.copy(), A, sm, shift=0.7, dimension=dim, lowest_level=g)
+        assert x.shape == (n, 1)
+        assert rel_err(x.ravel(), sp.linalg.spsolve(sp.csc_matrix(A - 0.7 * sp.eye(n)), f)) < 1e-11
+
+
+def test_many_columns_and_strided_views(trio):
+    solver, sm, processor = trio
+    rng = np.random.RandomState(2)
+    n, k = 256, 32                                     # the maximum number of columns of one call
+    A = H(sm, n)
+    F = rng.rand(n, k)
+    shifts = np.linspace(0.1, 0.9, k)
+    # lowest level 32: the smallest grid that is Gram-Schmidt'ed has 64 points (> k columns)
+    x = solver.vcycle_matrix(np.zeros((n, k)), F, A, sm, shifts=shifts, lowest_level=32)
+    y = S.vcycle_matrix(np.zeros((n, k)), F, A, SM, shifts=shifts, lowest_level=32)
+    assert rel_err(x, y) < 1e-8                        # 32 Gram-Schmidt'ed columns: conditioning, not kernels
+    with pytest.raises(ValueError):
+        solver.vcycle_matrix(np.zeros((n, 33)), rng.rand(n, 33), A, sm, shifts=np.zeros(33))
+    # column views (stride k) as the reference's callers pass them (UnitTests/vcycle_matrixTest.py:23)
+    X = rng.rand(n, 3)
+    out = solver.vcycle(X[:, 1], F[:, 0], A, sm)
+    assert rel_err(out, S.vcycle(X[:, 1].copy(), F[:, 0].copy(), A, SM)) < 1e-12
+    G = processor.gramschmidt(F[:, :5])
+    assert np.allclose(G, RefProcessor().gramschmidt(F[:, :5]), atol=1e-13)
+
+
+def test_non_power_of_two_and_ragged(trio, capsys):
+    solver, sm, _ = trio
+    assert solver.vcycle(np.ones(24), np.zeros(24), sm.laplacian(24), sm) is None
+    assert solver.vcycle(np.ones(36), np.zeros(36), sm.laplacian(6, "2d"), sm, dimension="2d") is None
+    assert "power of 2" in capsys.readouterr().out
+    with pytest.raises(ValueError):
+        solver.vcycle(np.ones(16), np.zeros(16), sm.laplacian(16), sm, lowest_level=3)
+    with pytest.raises(ValueError):
+        solver.vcycle_matrix(np.zeros((16, 2)), np.zeros((16, 2)), sm.laplacian(16), sm, shifts=np.zeros(3))
+
+
+def test_twogrid_two_dimensional(trio):
+    """The reference's twogrid cannot run in 2-D (MGCMTSolver.py:350); here it equals a V-cycle whose lowest
+    level is the next grid."""
+    solver, sm, _ = trio
+    A = H(sm, 16, "2d")
+    f = np.random.RandomState(4).rand(256)
+    a = solver.twogrid(np.zeros(256), f.copy(), A, sm, nu1=2, nu2=2, shift=0.4, dimension="2d")
+    b = solver.vcycle(np.zeros(256), f.copy(), A, sm, nu1=2, nu2=2, shift=0.4, dimension="2d", lowest_level=8)
+    assert rel_err(a, b) < 1e-13
+
+
+def test_plan_cache_reuse_and_shift_changes(trio):
+    """A driver's outer loop calls vcycle with the same operator and changing shifts: the cached plan must refactor
+    its coarsest level when the shift changes."""
+    solver, sm, _ = trio
+    A = H(sm, 128)
+    f = np.random.RandomState(5).rand(128)
+    for mu in (0.0, 0.9, 0.9, 3.8, 0.0):
+        x = solver.vcycle(np.zeros(128), f.copy(), A, sm, shift=mu, lowest_level=8)
+        assert rel_err(x, S.vcycle(np.zeros(128), f, A, SM, shift=mu, lowest_level=8)) < 1e-10, mu
+
+
+def test_one_dimensional_variable_coefficients(trio):
+    """1-D operators are general tridiagonals (a potential on the diagonal, PotWellSolver.py:150-153 style)."""
+    solver, sm, _ = trio
+    n = 128
+    V = np.where((np.arange(n) < 40) | (np.arange(n) >= 90), 25.0, 0.0)
+    A = H(sm, n) + sp.diags(V)
+    f = np.random.RandomState(6).rand(n)
+    for smo, rsmo in ((solver.wjacobi, S.wjacobi), (solver.gseidel, S.gseidel),
+                      (solver.gseidel_rb, lambda v, f, A, nu=4: S.gseidel_mc(v, f, A, nu=nu, dimension="1d"))):
+        x = solver.vcycle(np.zeros(n), f.copy(), A, sm, nu1=2, nu2=2, smoother=smo, shift=1.1, lowest_level=4)
+        y = S.vcycle(np.zeros(n), f, A, SM, nu1=2, nu2=2, smoother=rsmo, shift=1.1, lowest_level=4)
+        assert rel_err(x, y) < 1e-10

@@ -85,3 +85,23 @@ def test_sharded_plan_single_rank_on_gpu(hip_only):
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "SHARDED_WORLD1_OK" in out.stdout
+
+
+@pytest.mark.parametrize("g,kind,omega,nu", [(1024, _lib.WJACOBI, 2. / 3., 2), (1024, _lib.GS_MC, 1.0, 3), (512, _lib.WJACOBI, 2. / 3., 1)])
+def test_graph_replay_equals_eager(hip_only, g, kind, omega, nu):
+    """mgcmt_vcycle replays a captured HIP graph from its second call on; results must be those of eager launches,
+    also when the shift changes between cycles (coarsest-level factorisation redone outside the graph) and when
+    the number of buffer swaps per cycle is odd (two graphs alternate)."""
+    f = np.random.RandomState(3).rand(g * g)
+    outs = []
+    for graph in (1, 0):
+        p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
+        p.set_option(_lib.OPT_GRAPH, graph)
+        p.upload(0, _lib.SLOT_F, 0, f)
+        p.fill(0, _lib.SLOT_V, 0, 0.0)
+        for i in range(6):
+            p.set_shifts([0.0 if i < 3 else 0.5])
+            p.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu)
+        outs.append(p.download(0, _lib.SLOT_V, 0))
+        p.close()
+    assert np.array_equal(outs[0], outs[1])
