@@ -155,7 +155,68 @@ __global__ void __launch_bounds__(kBandThreads) k_band_solve(KBand b, KVec rhs, 
   }
 }
 
+// Explicit inverse of the factored coarsest-level matrix (small: lowest_level^2 unknowns): thread j runs the
+// whole forward / backward substitution for the unit vector e_j on its own column, stored transposed
+// (inv[i*n + j]) so that the accesses of neighbouring threads coalesce.  One solve per cycle then is a dense
+// matrix-vector product instead of 2n barrier-separated substitution steps.
+__global__ void k_band_invert(KBand b, double* __restrict__ inv_all, long inv_stride) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = blockIdx.y;
+  const long n = b.n;
+  if (j >= n) return;
+  const double* ab = b.ab + q * b.ab_stride;
+  const int* piv = b.piv + q * b.piv_stride;
+  double* x = inv_all + q * inv_stride + j;  // element i at x[i*n]
+  const int kl = b.kl, width = b.width;
+  for (long i = 0; i < n; ++i) x[i * n] = i == j ? 1.0 : 0.0;
+  for (long c = 0; c < n; ++c) {
+    const long p = piv[c];
+    if (p != c) {
+      const double t = x[c * n];
+      x[c * n] = x[p * n];
+      x[p * n] = t;
+    }
+    const double xc = x[c * n];
+    if (xc != 0.0) {
+      const long last = c + kl < n - 1 ? c + kl : n - 1;
+      for (long r = c + 1; r <= last; ++r) x[r * n] -= ab[r * width + (c - r + kl)] * xc;
+    }
+  }
+  for (long c = n - 1; c >= 0; --c) {
+    const double xc = x[c * n] / ab[c * width + kl];
+    x[c * n] = xc;
+    const long first = c - 2L * kl > 0 ? c - 2L * kl : 0;
+    for (long r = first; r < c; ++r) x[r * n] -= ab[r * width + (c - r + kl)] * xc;
+  }
+}
+
+// x = inv * f with inv stored transposed (inv[i*n + j] = (A^-1)[i][j]... element (row i, column j) at [i*n + j])
+__global__ void __launch_bounds__(kBandThreads) k_dense_solve(long n, const double* __restrict__ inv_all, long inv_stride, KVec rhs, KVec xx) {
+  __shared__ double s_f[1024];
+  const int q = blockIdx.y;
+  const double* inv = inv_all + q * inv_stride;
+  const double* f = rhs.p + q * rhs.stride;
+  double* x = xx.p + q * xx.stride;
+  for (long c = threadIdx.x; c < n; c += blockDim.x) s_f[c] = f[c];
+  __syncthreads();
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // row i of the inverse is contiguous: inv[i*n + j]
+  const double* row = inv + i * n;
+  double acc = 0.0;
+  for (long j = 0; j < n; ++j) acc += row[j] * s_f[j];
+  x[i] = acc;
+}
+
 }  // namespace
+
+void launch_band_invert(hipStream_t s, KBand b, double* inv, long inv_stride, int k) {
+  hipLaunchKernelGGL(k_band_invert, dim3((unsigned)((b.n + 63) / 64), (unsigned)k), dim3(64), 0, s, b, inv, inv_stride);
+}
+
+void launch_dense_solve(hipStream_t s, long n, const double* inv, long inv_stride, KVec rhs, KVec x, int k) {
+  hipLaunchKernelGGL(k_dense_solve, dim3((unsigned)((n + kBandThreads - 1) / kBandThreads), (unsigned)k), dim3(kBandThreads), 0, s, n, inv, inv_stride, rhs, x);
+}
 
 void launch_band_assemble(hipStream_t s, KGrid g, KOp op, const double* shifts, KBand b, int k) {
   hipLaunchKernelGGL(k_band_assemble, dim3((unsigned)((b.n + 255) / 256), (unsigned)k), dim3(256), 0, s, g, op, shifts, b);

@@ -34,12 +34,12 @@ namespace {
 #define MGCMT_FUSED_DEPTH 4
 #endif
 #ifndef MGCMT_FUSED_WAVES
-#define MGCMT_FUSED_WAVES 4
+#define MGCMT_FUSED_WAVES 1
 #endif
 constexpr int kDepth = MGCMT_FUSED_DEPTH;         // rows per prefetch batch (two batches of registers)
 constexpr int kWavesPerBlock = MGCMT_FUSED_WAVES;
 #ifndef MGCMT_FUSED_DEPTH9
-#define MGCMT_FUSED_DEPTH9 2
+#define MGCMT_FUSED_DEPTH9 1
 #endif
 constexpr int kDepth9 = MGCMT_FUSED_DEPTH9;  // 9-point policies carry wider windows: shallower batches keep two or three waves per SIMD
 
@@ -472,6 +472,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
 }
 
 long g_fused_rows_override = MGCMT_FUSED_ROWS;  // 0 = automatic
+#ifndef MGCMT_FUSED_MIN_ROWS
+#define MGCMT_FUSED_MIN_ROWS 4
+#endif
+constexpr long kFusedMinRows = MGCMT_FUSED_MIN_ROWS;  // shortest chunk: a wave's march has a fixed cost per row step
 
 template <class OP, int KIND, int NSWEEP, bool PROLONG, bool RESTRICT, bool ZERO_IN>
 void launch_one(hipStream_t s, FusedArgs a, int k) {
@@ -500,7 +504,7 @@ void launch_one(hipStream_t s, FusedArgs a, int k) {
     long chunks = (long)(0.9 * resident_blocks) / (groups * k);
     if (chunks < 1) chunks = 1;
     rows = (a.nr + chunks - 1) / chunks;
-    if (rows < 32) rows = 32;
+    if (rows < kFusedMinRows) rows = kFusedMinRows;
   }
   if (rows > a.nr) rows = a.nr;
   rows = (rows + 1) & ~1L;
@@ -528,10 +532,16 @@ void launch_mode(hipStream_t s, const FusedArgs& a, int mode, int k) {
 
 void fused_set_rows(long rows) { g_fused_rows_override = rows; }
 
+#ifndef MGCMT_FUSED_MIN_COLS
+#define MGCMT_FUSED_MIN_COLS 16
+#endif
+constexpr long kFusedMinCols = MGCMT_FUSED_MIN_COLS;
+
 // Levels the fused kernels cover: 2-D, constant 5-point or two-term separable 9-point operators (the
-// scaled Laplacian and all its Galerkin coarsenings), at least one 128-column window wide.
+// scaled Laplacian and all its Galerkin coarsenings).  Narrow levels run too (one partly filled wave per
+// chunk): a fused pass there replaces four to nine tiny launches, which is what small levels cost.
 bool fused_supported(const KGrid& g, const KOp& op) {
-  return g.coarsen_rows && g.nr >= 2 && g.nc >= 128 && (g.nc & 1) == 0 && (op.five_point || op.nine_const || op.nterms == 2);
+  return g.coarsen_rows && g.nr >= 4 && g.nc >= kFusedMinCols && (g.nc & 1) == 0 && (g.nr & 1) == 0 && (op.five_point || op.nine_const || op.nterms == 2);
 }
 
 // sweeps one pass can fuse: a 9-point four-colour sweep is already four pipeline stages

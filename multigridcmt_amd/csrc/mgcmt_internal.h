@@ -91,5 +91,8 @@ struct KBand {
 void launch_band_assemble(hipStream_t s, KGrid g, KOp op, const double* shifts, KBand b, int k);
 void launch_band_factor(hipStream_t s, KBand b, int k);
 void launch_band_solve(hipStream_t s, KBand b, KVec rhs, KVec x, int k);
+// explicit inverse (n <= 1024 unknowns) and the dense solve x = inv * rhs that replaces the substitutions
+void launch_band_invert(hipStream_t s, KBand b, double* inv, long inv_stride, int k);
+void launch_dense_solve(hipStream_t s, long n, const double* inv, long inv_stride, KVec rhs, KVec x, int k);
 
 }  // namespace mgcmt

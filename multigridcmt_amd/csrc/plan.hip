@@ -100,6 +100,7 @@ struct DevOp {
 
 struct BandState {
   KBand b{};
+  double* inv = nullptr;  // explicit inverse per vector when the coarsest level has at most 1024 unknowns
   bool valid = false;
   int k = 0;
   std::vector<double> shifts;
@@ -410,6 +411,7 @@ int coarse_solve_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
     B.b.piv_stride = n;
     MG_HIP(hipMalloc((void**)&B.b.ab, sizeof(double) * B.b.ab_stride * p->nvec));
     MG_HIP(hipMalloc((void**)&B.b.piv, sizeof(int) * B.b.piv_stride * p->nvec));
+    if (n <= 1024) MG_HIP(hipMalloc((void**)&B.inv, sizeof(double) * n * n * p->nvec));
   }
   bool same = B.valid && B.k >= k;
   if (same)
@@ -417,11 +419,13 @@ int coarse_solve_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
   if (!same) {
     launch_band_assemble(s, p->kgrid(l), L.dA.k, p->d_shifts, B.b, k);
     launch_band_factor(s, B.b, k);
+    if (B.inv) launch_band_invert(s, B.b, B.inv, n * n, k);
     B.valid = true;
     B.k = k;
     B.shifts.assign(p->h_shifts.begin(), p->h_shifts.begin() + k);
   }
-  launch_band_solve(s, B.b, p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_V), k);
+  if (B.inv) launch_dense_solve(s, n, B.inv, n * n, p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_V), k);
+  else launch_band_solve(s, B.b, p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_V), k);
   return post_launch();
 }
 
@@ -529,6 +533,7 @@ int ensure_coarse_factor(mgcmt_plan* p, int l, int k, hipStream_t s) {
   if (!B.b.ab) return MGCMT_OK;  // first use: coarse_solve_impl allocates and factors
   launch_band_assemble(s, p->kgrid(l), L.dA.k, p->d_shifts, B.b, k);
   launch_band_factor(s, B.b, k);
+  if (B.inv) launch_band_invert(s, B.b, B.inv, (long)B.b.n * B.b.n, k);
   B.valid = true;
   B.k = k;
   B.shifts.assign(p->h_shifts.begin(), p->h_shifts.begin() + k);
@@ -678,6 +683,7 @@ int mgcmt_plan_destroy(mgcmt_plan* p) {
     for (double* q : L.dM.owned) (void)hipFree(q);
     if (L.band.b.ab) (void)hipFree(L.band.b.ab);
     if (L.band.b.piv) (void)hipFree(L.band.b.piv);
+    if (L.band.inv) (void)hipFree(L.band.inv);
   }
   for (auto& g : p->graphs)
     if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);

@@ -35,8 +35,9 @@ def test_2d_published_table(hip_only):
     published_mg = np.array([1.96901685, 4.92197738, 4.92197786, 7.87499665, 9.84169385, 9.84166931])
     lanczos = np.array([1.96901511, 4.92195391, 4.92195391, 7.87489271, 9.84157268, 9.84157268])
     got = np.sort(out["eigenvalues"])
-    assert np.allclose(got, lanczos, rtol=0, atol=2e-4)
-    assert np.allclose(got, np.sort(published_mg), rtol=0, atol=2e-4)
+    assert abs(got[0] - published_mg[0]) < 5e-9                     # the non-degenerate ground state: every printed digit
+    assert np.allclose(got, np.sort(published_mg), rtol=0, atol=2e-4)   # degenerate pairs depend on ARPACK's rotation of the guesses
+    assert np.allclose(got, lanczos, rtol=0, atol=4e-4)                 # five single-V-cycle steps: the method's own accuracy
     assert np.allclose(lanczos, drivers.exact_box_eigenvalues(128, "2d", 6), rtol=0, atol=1e-7)
 
 
