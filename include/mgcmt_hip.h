@@ -144,7 +144,10 @@ int mgcmt_normalize(mgcmt_plan* plan, int level, int slot, int k, void* stream);
  * mgcmt_fused_pass: ONE fused row-streaming pass on `level`, V <- nsweep sweeps of `kind` (MGCMT_WJACOBI or
  * MGCMT_GS_MC) applied to V, optionally preceded by V += P V[level+1] (mode 1, MGCMTSolver.py:323-324) or
  * followed by F[level+1] <- R (F - (A - mu I) V) (mode 2, :315); adding 4 to mode 0 or 2 declares the incoming V
- * to be zero (it is then neither read nor required to have been cleared, :316).  The pass reads MGCMT_HALO_ROWS halo rows of V
+ * to be zero (it is then neither read nor required to have been cleared, :316); adding 8 to mode 2 suppresses the
+ * store of the smoothed V ("recompute instead of store": a later mode-1 pass with (npre << 4) added re-runs those
+ * npre sweeps from the untouched V before it adds the correction — also with 4 when that V is the zero iterate).
+ * The pass reads MGCMT_HALO_ROWS halo rows of V
  * and F (and of V[level+1] in mode 1) around a strip.  mgcmt_fused_max_sweeps: sweeps one pass can take on that
  * level (0 = the level is not covered by the fused kernels). */
 int mgcmt_fused_pass(mgcmt_plan* plan, int level, int kind, int nsweep, double omega, int mode, int k, void* stream);
@@ -155,6 +158,8 @@ int mgcmt_fused_max_sweeps(const mgcmt_plan* plan, int level, int kind, int* max
 typedef enum mgcmt_option {
   MGCMT_OPT_FUSED = 0,
   MGCMT_OPT_FUSED_ROWS = 1, /* tuning: rows per wave chunk, 0 = auto */
+  MGCMT_OPT_RECOMPUTE = 3,  /* default 1: on levels of >= 2^22 points down-leg passes do not store the pre-smoothed iterate and
+                               up-leg passes recompute it; 2: on every fused level; 0: never */
   MGCMT_OPT_GRAPH = 2       /* default 1: mgcmt_vcycle replays its launch sequence as a HIP graph from the second call on */
 } mgcmt_option;
 int mgcmt_plan_set_option(mgcmt_plan* plan, int option, int value);
@@ -165,7 +170,9 @@ int mgcmt_time_smoother(mgcmt_plan* plan, int level, int kind, int nu, double om
                         void* stream);
 
 /* empirical HBM ceilings for bench.py: streams the plan's level-`level` vectors (slots V, F -> T) with a
- * plain grid-stride kernel; kind 0 copy (16 B/point), 1 triad (24 B/point), 2 read-only (8 B/point);
+ * plain grid-stride kernel; kind 0 copy (16 B/point), 1 triad (24 B/point), 2 read-only (8 B/point); kinds 3/4/5 use
+ * the fused kernels' access pattern instead (128-column windows marching down `blocks` rows): read 1 stream (8 B),
+ * read 2 (16 B), read 2 + write 1 (24 B); kinds 6/7/8 the same with overlapping, unaligned windows (124 of 128 kept);
  * returns the average milliseconds per launch */
 int mgcmt_bandwidth_probe(mgcmt_plan* plan, int level, int kind, int blocks, int reps, double* ms_out, void* stream);
 

@@ -93,6 +93,41 @@ __global__ void k_probe_read(long n2, const double2* __restrict__ a, double* __r
   if (acc == 12345.678) sink[0] = acc;  // keeps the loads alive without a store stream
 }
 
+// access-pattern probe: the fused kernels' pattern without their arithmetic — a wave reads (and optionally
+// writes) 1 KiB per row of nstreams arrays while marching down `rows` rows of an nc-wide grid
+__global__ void __launch_bounds__(64) k_probe_march(long nr, long nc, long rows, int nstreams, int do_write, int wout, const double* __restrict__ a,
+                                                    const double* __restrict__ b, double* __restrict__ out, double* __restrict__ sink) {
+  const long strips = (nc + wout - 1) / wout;
+  const long strip = blockIdx.x % strips, chunk = blockIdx.x / strips;
+  // wout < 128: overlapping, unaligned windows as in the fused kernels (only the wout inner columns are written)
+  long j = strip * wout - (128 - wout) / 2 + 2 * (threadIdx.x & 63);
+  const bool writer = 2 * (threadIdx.x & 63) >= (128 - wout) / 2 && 2 * (threadIdx.x & 63) < (128 - wout) / 2 + wout && j < nc;
+  j = j < 0 ? 0 : (j > nc - 2 ? nc - 2 : j);
+  const long r0 = chunk * rows, r1 = r0 + rows < nr ? r0 + rows : nr;
+  double acc = 0.0;
+  for (long r = r0; r < r1; r += 8) {
+    double2 x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long rr = r + u < nr ? r + u : nr - 1;
+      x[u] = *reinterpret_cast<const double2*>(a + rr * nc + j);
+      if (nstreams > 1) y[u] = *reinterpret_cast<const double2*>(b + rr * nc + j);
+      else y[u] = make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double sx = x[u].x + y[u].x, sy = x[u].y + y[u].y;
+      if (do_write) {
+        const long rr = r + u < nr ? r + u : nr - 1;
+        if (writer) *reinterpret_cast<double2*>(out + rr * nc + j) = make_double2(sx, sy);
+      } else {
+        acc += sx + sy;
+      }
+    }
+  }
+  if (acc == 12345.678) sink[0] = acc;
+}
+
 inline unsigned blocks_for(long n) {
   long b = (n + 255) / 256;
   if (b > 2048) b = 2048;
@@ -116,6 +151,11 @@ void launch_axpy_dev(hipStream_t s, long n, const double* alpha_dev, const doubl
 
 void launch_scale_dev(hipStream_t s, long n, const double* s_dev, int use_sqrt, double* x) {
   hipLaunchKernelGGL(k_scale_dev, dim3(blocks_for(n)), dim3(256), 0, s, n, s_dev, use_sqrt, x);
+}
+
+void launch_probe_march(hipStream_t s, long nr, long nc, long rows, int nstreams, int do_write, int wout, const double* a, const double* b, double* out) {
+  const long strips = (nc + wout - 1) / wout, chunks = (nr + rows - 1) / rows;
+  hipLaunchKernelGGL(k_probe_march, dim3((unsigned)(strips * chunks)), dim3(64), 0, s, nr, nc, rows, nstreams, do_write, wout, a, b, out, out);
 }
 
 void launch_probe(hipStream_t s, int kind, long n, const double* a, const double* b, double* out, int blocks) {

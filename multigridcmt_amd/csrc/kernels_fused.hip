@@ -1,534 +1,19 @@
-// Row-streaming fused kernels — the V-cycle's hot kernels on large 2-D levels: constant 5-point
-// operators (the scaled / shifted Laplacian of MGCMTStencilMaker.py:15-25) and the separable 9-point
-// Galerkin operators R*A*P of the coarser levels (MGCMTSolver.py:318).
-//
-// One launch does, in a single pass over the level (read v, read f, write v'):
-//     [prolong + correct]  ->  NSWEEP smoothing sweeps  ->  [residual + full-weighting restriction]
-// i.e. MGCMTSolver.py:323-326 or :313-315 fused.  Algorithmic traffic per fine point: 24 B for the
-// pass (+2 B for the coarse array), whatever NSWEEP is, instead of 24 B per sweep plus 2 x 18 B for
-// the transfers.
-//
-// Mapping (wave64, no LDS, no barriers): a wave owns a window of 128 columns (2 per lane, 16-byte
-// loads/stores) and marches down a chunk of rows_per_chunk rows.  Every sweep is a pipeline stage
-// that lags one row behind the previous one; a stage keeps a three-row window of its input in
-// registers and gets the lateral neighbours from the adjacent lanes (wave shuffles).  Values at the
-// wave's edges become invalid one column per stage, so a window overlaps its neighbours by `halo`
-// columns per side and by S(+1) rows at the chunk ends; those are recomputed redundantly (they come
-// from L2, not HBM: vertically adjacent chunks are scheduled back-to-back on the same XCD).  The pass
-// is out of place (v -> v'), so neighbouring windows never see half-updated data.
-//
-// Stages: weighted Jacobi = one stage per sweep; red-black Gauss-Seidel = a red ((i+j) odd) and a
-// black stage per sweep — the same update order as the multicolour smoother of kernels_stencil.hip
-// restricted to a 5-point operator.  Rows/columns outside the global grid are held at zero
-// (Dirichlet ghosts), rows in [row_lo,row_hi) outside the chunk belong to neighbours.
-#include "mgcmt_internal.h"
+// Dispatcher of the fused row-streaming passes (kernel template: fused_kernel.h; instantiations per operator
+// policy: kernels_fused_op5.hip, kernels_fused_op9c.hip, kernels_fused_op9.hip).
+#include "fused_kernel.h"
 
 namespace mgcmt {
 
 namespace {
-
 #ifndef MGCMT_FUSED_ROWS
 #define MGCMT_FUSED_ROWS 0
 #endif
-#ifndef MGCMT_FUSED_DEPTH
-#define MGCMT_FUSED_DEPTH 4
-#endif
-#ifndef MGCMT_FUSED_WAVES
-#define MGCMT_FUSED_WAVES 1
-#endif
-constexpr int kDepth = MGCMT_FUSED_DEPTH;         // rows per prefetch batch (two batches of registers)
-constexpr int kWavesPerBlock = MGCMT_FUSED_WAVES;
-#ifndef MGCMT_FUSED_DEPTH9
-#define MGCMT_FUSED_DEPTH9 1
-#endif
-constexpr int kDepth9 = MGCMT_FUSED_DEPTH9;  // 9-point policies carry wider windows: shallower batches keep two or three waves per SIMD
-
-struct FusedArgs {
-  const double* vin;
-  const double* f;
-  double* vout;
-  const double* ec;  // coarse correction to interpolate and add first (PROLONG)
-  double* rc;        // coarse right-hand side written last (RESTRICT)
-  long nr, nc;       // local rows / columns
-  long row_lo, row_hi;  // local rows that lie inside the global grid
-  long vstride, cstride;
-  long cnc;
-  double c0, cn, cw;                 // constant 5-point operator
-  double c9[3][3], c9row[3], c9col[3], c9corner;  // Galerkin levels of a constant operator (Op9c)
-  long last_row;                     // local index of the global last row
-  const double* X[kMaxTerms];        // separable 9-point operator: row / column factors (KOp layout)
-  const double* Y[kMaxTerms];
-  long ldx, ldy;
-  const double* shifts;
-  double omega;
-  int n_row_chunks, n_col_groups;
-  int rows_per_chunk;  // rows a wave marches over (even), plus the overlap
-};
-
-#ifndef MGCMT_FUSED_NT_STORE
-#ifdef __HIP__
-#define MGCMT_FUSED_NT_STORE 1  // measured: 2-4 % faster passes; the written vector is not re-read by this pass
-#else
-#define MGCMT_FUSED_NT_STORE 0
-#endif
-#endif
-#ifndef MGCMT_FUSED_NT_F
-#define MGCMT_FUSED_NT_F 0
-#endif
-#if MGCMT_FUSED_NT_STORE || MGCMT_FUSED_NT_F
-typedef double v2d_t __attribute__((ext_vector_type(2)));
-#endif
-
-// 16-byte accesses; the streamed-once operands optionally bypass the caches' retention (non-temporal)
-__device__ __forceinline__ double2 load2(const double* p) { return *reinterpret_cast<const double2*>(p); }
-__device__ __forceinline__ double2 load2_stream(const double* p) {
-#if MGCMT_FUSED_NT_F
-  const v2d_t t = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(p));
-  return make_double2(t.x, t.y);
-#else
-  return load2(p);
-#endif
-}
-__device__ __forceinline__ void store2_stream(double* p, double x, double y) {
-#if MGCMT_FUSED_NT_STORE
-  v2d_t t;
-  t.x = x;
-  t.y = y;
-  __builtin_nontemporal_store(t, reinterpret_cast<v2d_t*>(p));
-#else
-  *reinterpret_cast<double2*>(p) = make_double2(x, y);
-#endif
-}
-
-constexpr int round_even(int x) { return (x + 1) & ~1; }
-
-// ---- operator policies -------------------------------------------------------------------------
-// A policy evaluates, for one of the lane's two columns (COL 0 = ja, 1 = ja+1), the off-diagonal sum,
-// the diagonal of (A - mu I) and its reciprocal from the 3 x 3 neighbourhood n / c / s = row above /
-// own row / row below, each ordered west, centre, east.
-
-// constant 5-point operator: c0 on the diagonal, cn for the row neighbours, cw for the column ones
-struct Op5 {
-  static constexpr bool kNine = false;
-  double d, invd, cn, cw;
-  __device__ __forceinline__ void init(const FusedArgs& a, int q, long, long) {
-    d = a.c0 - a.shifts[q];
-    invd = 1.0 / d;
-    cn = a.cn;
-    cw = a.cw;
-  }
-  __device__ __forceinline__ void set_row(const FusedArgs&, long) {}
-  template <int COL>
-  __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
-    off = cn * (n[1] + s[1]) + cw * (c[0] + c[2]);
-    dg = d;
-    inv = invd;
-  }
-};
-
-// Galerkin coarsenings of a constant operator: every factor is Toeplitz except its last diagonal entry
-// (MGCMTSolver.py:318 with the one-sided P/R of MGCMTStencilMaker.py:27-78), so the 9 coefficients are
-// constants with corrections on the last row, the last column and the corner.  No coefficient loads.
-struct Op9c {
-  static constexpr bool kNine = true;
-  double cnw, cn_, cne, cw_, cc_, ce_, csw, cs_, cse;  // interior
-  double rw, rc, re;                                     // own-row coefficients on the last row
-  double kn, kc, ks, kcr;                                // centre-column coefficients on the last column (kcr: corner)
-  double mu;
-  double lastb;  // 1.0 when column ja+1 is the last column, else 0.0 (arithmetic blends, no data-dependent selects of members)
-  long last_row_index;
-  double lr;     // 1.0 on the last row
-  double i00, ir, ic, irc;
-  __device__ __forceinline__ void init(const FusedArgs& a, int q, long ja, long nc) {
-    cnw = a.c9[0][0]; cn_ = a.c9[0][1]; cne = a.c9[0][2];
-    cw_ = a.c9[1][0]; cc_ = a.c9[1][1]; ce_ = a.c9[1][2];
-    csw = a.c9[2][0]; cs_ = a.c9[2][1]; cse = a.c9[2][2];
-    // stored as differences to the interior values so that a row / column flag blends them in
-    rw = a.c9row[0] - cw_; rc = a.c9row[1] - cc_; re = a.c9row[2] - ce_;
-    kn = a.c9col[0] - cn_; kc = a.c9col[1] - cc_; ks = a.c9col[2] - cs_;
-    kcr = a.c9corner - a.c9row[1] - a.c9col[1] + cc_;
-    mu = a.shifts[q];
-    lastb = (ja + 1 == nc - 1) ? 1.0 : 0.0;
-    last_row_index = a.last_row;
-    lr = 0.0;
-    // reciprocals of the four possible diagonals (interior, last row, last column, corner), as blends
-    i00 = 1.0 / (cc_ - mu);
-    const double i10 = 1.0 / (a.c9row[1] - mu), i01 = 1.0 / (a.c9col[1] - mu), i11 = 1.0 / (a.c9corner - mu);
-    ir = i10 - i00;
-    ic = i01 - i00;
-    irc = i11 - i10 - i01 + i00;
-  }
-  __device__ __forceinline__ void set_row(const FusedArgs&, long row) { lr = row == last_row_index ? 1.0 : 0.0; }
-  template <int COL>
-  __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
-    const double lc = COL == 1 ? lastb : 0.0;
-    const double w = cw_ + lr * rw, e = ce_ + lr * re;
-    const double vn = cn_ + lc * kn, vs = cs_ + lc * ks;
-    const double vc = cc_ + lr * rc + lc * kc + (lr * lc) * kcr;
-    off = cnw * n[0] + vn * n[1] + cne * n[2] + w * c[0] + e * c[2] + csw * s[0] + vs * s[1] + cse * s[2];
-    dg = vc - mu;
-    inv = i00 + lr * ir + lc * ic + (lr * lc) * irc;
-  }
-};
-
-// general separable 9-point operator  sum_m X_m (x) Y_m : the lane keeps the column factors of its two
-// columns in registers; the row factors of the current row are wave-uniform scalar loads
-template <int M>
-struct Op9 {
-  static constexpr bool kNine = true;
-  double mu;
-  double ya[M][3], yb[M][3];  // lower, diag, upper of Y_m at columns ja, ja+1
-  double x[M][3];             // lower, diag, upper of X_m at the row being updated
-  __device__ __forceinline__ void init(const FusedArgs& a, int q, long ja, long nc) {
-    mu = a.shifts[q];
-    const long j = ja < 0 ? 0 : (ja > nc - 2 ? nc - 2 : ja);
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        ya[m][p] = a.Y[m][p * a.ldy + j];
-        yb[m][p] = a.Y[m][p * a.ldy + j + 1];
-      }
-  }
-  __device__ __forceinline__ void set_row(const FusedArgs& a, long row) {
-    const long r = row < a.row_lo ? a.row_lo : (row >= a.row_hi ? a.row_hi - 1 : row);
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) x[m][p] = a.X[m][p * a.ldx + r];
-  }
-  template <int COL>
-  __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
-    double o = 0.0, dd = 0.0;
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const double* y = COL == 0 ? ya[m] : yb[m];
-      const double rn = y[0] * n[0] + y[1] * n[1] + y[2] * n[2];
-      const double rc = y[0] * c[0] + y[2] * c[2];
-      const double rs = y[0] * s[0] + y[1] * s[1] + y[2] * s[2];
-      o += x[m][0] * rn + x[m][1] * rc + x[m][2] * rs;
-      dd += x[m][1] * y[1];
-    }
-    off = o;
-    dg = dd - mu;
-    inv = 1.0 / dg;
-  }
-};
-
-enum { kJacobi = 0, kRedBlack = 1, kFourColour = 2 };
-
-template <class OP, int KIND, int NSWEEP, bool PROLONG, bool RESTRICT>
-struct FusedShape {
-  static constexpr int S = KIND == kJacobi ? NSWEEP : (KIND == kRedBlack ? 2 * NSWEEP : 4 * NSWEEP);  // pipeline stages
-  static constexpr int E = RESTRICT ? 1 : 0;
-  static constexpr int halo = round_even(S + (RESTRICT ? 2 : (PROLONG ? 1 : 0)));  // lateral, per side
-  static constexpr int wout = 128 - 2 * halo;                                     // columns a wave produces
-};
-
-// ZERO_IN: the incoming iterate is identically zero (the error equation on a coarser level starts from
-// zero, MGCMTSolver.py:316): V is not read at all and nobody has to clear it first.
-template <class OP, int KIND, int NSWEEP, bool PROLONG, bool RESTRICT, bool ZERO_IN>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
-  using Shape = FusedShape<OP, KIND, NSWEEP, PROLONG, RESTRICT>;
-  constexpr int S = Shape::S, E = Shape::E, HALO = Shape::halo, WOUT = Shape::wout;
-  constexpr bool NINE = OP::kNine;
-  constexpr int WN = NINE ? S + E : 1;  // windows that also keep the lateral neighbours
-  constexpr int D = NINE ? kDepth9 : kDepth;  // rows per prefetch batch
-
-  // workgroup -> (column group, row chunk): blocks b and b+8 run on the same XCD, so one XCD walks
-  // down the chunks of one column group and the overlapping rows are re-read from its own L2
-  const int b = blockIdx.x;
-  const int xcd = b & 7, seq = b >> 3;
-  const int chunk = seq % a.n_row_chunks;
-  const int group = xcd + 8 * (seq / a.n_row_chunks);
-  if (group >= a.n_col_groups) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long strip = (long)group * kWavesPerBlock + wave;
-  if (strip * WOUT >= a.nc) return;  // wave-uniform
-  const int q = blockIdx.y;
-
-  const long ja = strip * WOUT - HALO + 2 * lane;  // this lane's columns: ja (even), ja + 1
-  const bool col_in = ja >= 0 && ja < a.nc;
-  const bool col_out = col_in && 2 * lane >= HALO && 2 * lane < HALO + WOUT;
-  const long jc = ja >> 1;  // coarse column of the pair
-  const bool ccol_in = jc >= 0 && jc < a.cnc;
-
-  const double* __restrict__ vin = a.vin + q * a.vstride;
-  const double* __restrict__ fin = a.f + q * a.vstride;
-  double* __restrict__ vout = a.vout + q * a.vstride;
-  const double* __restrict__ ec = PROLONG ? a.ec + q * a.cstride : nullptr;
-  double* __restrict__ rc = RESTRICT ? a.rc + q * a.cstride : nullptr;
-
-  const double omega = a.omega;
-  const long nc = a.nc;
-
-  const long r_begin = (long)chunk * a.rows_per_chunk;
-  const long r_end = r_begin + a.rows_per_chunk < a.nr ? r_begin + a.rows_per_chunk : a.nr;
-  const long rstart = r_begin - (S + E);
-  const long rstop = r_end + S + 2 * E;  // rows [rstart, rstop) are read
-
-  auto row_ok = [&](long row) { return row >= a.row_lo && row < a.row_hi; };
-
-  // Loads are unconditional (addresses clamped into the allocation, values masked when they are
-  // consumed): with no branch around a load the compiler's vmcnt bookkeeping stays exact.
-  const long ja_ld = ja < 0 ? 0 : (ja > nc - 2 ? nc - 2 : ja);
-  const long jc_ld = jc < 0 ? 0 : (jc > a.cnc - 1 ? a.cnc - 1 : jc);
-  const long crow_lo = (a.row_lo >> 1) - 1, crow_hi = (a.row_hi - 1) >> 1;  // coarse rows that may be read
-
-  OP op;
-  op.init(a, q, ja, nc);
-
-  // Two register sets A/B of kDepth rows each, used alternately: one is refilled while the other is
-  // consumed, so every load has kDepth rows of work between its issue and its use.
-  struct Row {
-    double2 v, f;
-    double e;
-  };
-  Row setA[D], setB[D];
-  auto fetch = [&](long row, Row& r) __attribute__((always_inline)) {
-    const long rl = row < a.row_lo ? a.row_lo : (row >= a.row_hi ? a.row_hi - 1 : row);
-    if (ZERO_IN) r.v = make_double2(0.0, 0.0);
-    else r.v = load2(vin + rl * nc + ja_ld);
-    r.f = load2_stream(fin + rl * nc + ja_ld);
-    r.e = 0.0;
-    if (PROLONG) {
-      const long I = rl >> 1;
-      r.e = ec[(I < crow_lo ? crow_lo : (I > crow_hi ? crow_hi : I)) * a.cnc + jc_ld];
-    }
-  };
-#pragma unroll
-  for (int u = 0; u < D; ++u) fetch(rstart + u, setA[u]);
-
-  // stage windows: w[s] is the input of stage s+1; w[S] (RESTRICT) the input of the residual stage.
-  // [0] row above, [1] the row being updated, [2] row below; wl / wr: values left of ja / right of ja+1
-  double wa[S + E][3], wb[S + E][3], wl[WN][3], wr[WN][3];
-  double fa[S + E + 1], fb[S + E + 1];
-#pragma unroll
-  for (int s = 0; s < S + E; ++s)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) wa[s][r] = wb[s][r] = 0.0;
-#pragma unroll
-  for (int s = 0; s < WN; ++s)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) wl[s][r] = wr[s][r] = 0.0;
-#pragma unroll
-  for (int s = 0; s <= S + E; ++s) fa[s] = fb[s] = 0.0;
-
-  double e_prev = 0.0;  // coarse row of the previous fine row (PROLONG)
-  if (PROLONG) {
-    // coarse row of fine row rstart-1 (used when rstart is even); row (row_lo>>1)-1 is the halo row
-    const long I = (rstart - 1) >> 1;
-    if (ccol_in && I >= crow_lo && I <= crow_hi) e_prev = ec[I * a.cnc + jc];
-  }
-  double racc = 0.0;  // running full-weighting sum of the current coarse row (RESTRICT)
-
-  // push a finished row into window s (and, for 9-point operators, fetch its lateral neighbours)
-  auto push = [&](int s, double na, double nb) __attribute__((always_inline)) {
-    wa[s][0] = wa[s][1];
-    wa[s][1] = wa[s][2];
-    wa[s][2] = na;
-    wb[s][0] = wb[s][1];
-    wb[s][1] = wb[s][2];
-    wb[s][2] = nb;
-    if (NINE) {
-      wl[s][0] = wl[s][1];
-      wl[s][1] = wl[s][2];
-      wl[s][2] = __shfl_up(nb, 1);
-      wr[s][0] = wr[s][1];
-      wr[s][1] = wr[s][2];
-      wr[s][2] = __shfl_down(na, 1);
-    }
-  };
-  // neighbourhood of column ja (COL 0) / ja+1 (COL 1) in window s, handed to the operator policy
-  auto eval_a = [&](int s, double& off, double& dg, double& inv) __attribute__((always_inline)) {
-    if constexpr (NINE) {
-      const double n[3] = {wl[s][0], wa[s][0], wb[s][0]}, c[3] = {wl[s][1], wa[s][1], wb[s][1]}, so[3] = {wl[s][2], wa[s][2], wb[s][2]};
-      op.template eval<0>(n, c, so, off, dg, inv);
-    } else {
-      const double left = __shfl_up(wb[s][1], 1);
-      const double n[3] = {0.0, wa[s][0], 0.0}, c[3] = {left, wa[s][1], wb[s][1]}, so[3] = {0.0, wa[s][2], 0.0};
-      op.template eval<0>(n, c, so, off, dg, inv);
-    }
-  };
-  auto eval_b = [&](int s, double& off, double& dg, double& inv) __attribute__((always_inline)) {
-    if constexpr (NINE) {
-      const double n[3] = {wa[s][0], wb[s][0], wr[s][0]}, c[3] = {wa[s][1], wb[s][1], wr[s][1]}, so[3] = {wa[s][2], wb[s][2], wr[s][2]};
-      op.template eval<1>(n, c, so, off, dg, inv);
-    } else {
-      const double right = __shfl_down(wa[s][1], 1);
-      const double n[3] = {0.0, wb[s][0], 0.0}, c[3] = {wa[s][1], wb[s][1], right}, so[3] = {0.0, wb[s][2], 0.0};
-      op.template eval<1>(n, c, so, off, dg, inv);
-    }
-  };
-
-  // one marching step: consume the prefetched row `row`, run every stage one row further
-  auto step = [&](const long row, const Row& in) __attribute__((always_inline)) {
-    const bool in_dom = col_in && row_ok(row);
-    double ina = in_dom ? in.v.x : 0.0, inb = in_dom ? in.v.y : 0.0;
-    const double fna = in_dom ? in.f.x : 0.0, fnb = in_dom ? in.f.y : 0.0;
-
-    if (PROLONG) {
-      // interpolation along the row: odd fine column takes c[J], even takes (c[J-1] + c[J]) / 2
-      const double e_cur = (ccol_in && row_ok(row)) ? in.e : 0.0;
-      const double el = __shfl_up(e_cur, 1), pl = __shfl_up(e_prev, 1);
-      double ca = 0.5 * (el + e_cur), cb = e_cur;
-      if ((row & 1) == 0) {  // even fine row: mean of coarse rows I-1 and I
-        ca = 0.5 * (0.5 * (pl + e_prev) + ca);
-        cb = 0.5 * (e_prev + cb);
-      }
-      if (in_dom) {
-        ina += ca;
-        inb += cb;
-      }
-      e_prev = e_cur;
-    }
-
-#pragma unroll
-    for (int s = S + E; s > 0; --s) {
-      fa[s] = fa[s - 1];
-      fb[s] = fb[s - 1];
-    }
-    fa[0] = fna;
-    fb[0] = fnb;
-
-    double oa = ina, ob = inb;  // output of the previous stage = next input row
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      push(s, oa, ob);
-      const long rs = row - (s + 1);  // the row this stage completes now
-      const double ca = wa[s][1], cb = wb[s][1];
-      const bool live = col_in && row_ok(rs);  // outside the grid the value stays zero
-      bool upd_a = true, upd_b = true;
-      if (KIND == kRedBlack) {
-        const bool red = (s & 1) == 0;
-        const bool row_odd = (rs & 1) != 0;
-        upd_a = red == row_odd;  // column ja is even: it is red ((i+j) odd) iff the row is odd
-        upd_b = !upd_a;
-      } else if (KIND == kFourColour) {
-        // colours (i%2, j%2) in the order (0,1),(1,0),(0,0),(1,1)
-        const int c = s & 3;
-        const int cra = (c == 1 || c == 3) ? 1 : 0, ccb = (c == 0 || c == 3) ? 1 : 0;
-        const bool row_on = (int)(rs & 1) == cra;
-        upd_a = row_on && ccb == 0;
-        upd_b = row_on && ccb == 1;
-      }
-      double na = ca, nb = cb;
-      if (upd_a || upd_b) {  // wave-uniform
-        op.set_row(a, rs);
-        if (upd_a) {
-          double off, dg, inv;
-          eval_a(s, off, dg, inv);
-          na = ca + omega * ((fa[s + 1] - (off + dg * ca)) * inv);
-        }
-        if (upd_b) {
-          double off, dg, inv;
-          eval_b(s, off, dg, inv);
-          nb = cb + omega * ((fb[s + 1] - (off + dg * cb)) * inv);
-        }
-      }
-      oa = live ? na : 0.0;
-      ob = live ? nb : 0.0;
-    }
-
-    const long rout = row - S;
-    if (col_out && rout >= r_begin && rout < r_end) store2_stream(vout + rout * nc + ja, oa, ob);
-
-    if (RESTRICT) {
-      push(S, oa, ob);
-      const long rr = row - (S + 1);  // residual row completed now
-      const double ca = wa[S][1], cb = wb[S][1];
-      op.set_row(a, rr);
-      double offa, offb, dga, dgb, inva, invb;
-      eval_a(S, offa, dga, inva);
-      eval_b(S, offb, dgb, invb);
-      double ra = 0.0, rb = 0.0;
-      if (col_in && row_ok(rr)) {
-        ra = fa[S + 1] - (offa + dga * ca);
-        rb = fb[S + 1] - (offb + dgb * cb);
-      }
-      const double rnext = __shfl_down(ra, 1);  // residual at column ja + 2
-      const double h = 0.25 * ra + 0.5 * rb + 0.25 * rnext;
-      if ((rr & 1) == 0) {
-        const long I = (rr >> 1) - 1;  // coarse row closed by fine row rr = 2I + 2
-        if (col_out && ccol_in && 2 * I >= r_begin && 2 * I < r_end) rc[I * a.cnc + jc] = racc + 0.25 * h;
-        racc = 0.25 * h;
-      } else {
-        racc += 0.5 * h;
-      }
-    }
-  };
-
-  // Batches: fetch a whole set, then process the other one.
-  for (long base = rstart; base < rstop; base += 2 * D) {
-#pragma unroll
-    for (int u = 0; u < D; ++u) fetch(base + D + u, setB[u]);
-#pragma unroll
-    for (int u = 0; u < D; ++u) step(base + u, setA[u]);
-#pragma unroll
-    for (int u = 0; u < D; ++u) fetch(base + 2 * D + u, setA[u]);
-#pragma unroll
-    for (int u = 0; u < D; ++u) step(base + D + u, setB[u]);
-  }
-}
-
 long g_fused_rows_override = MGCMT_FUSED_ROWS;  // 0 = automatic
-#ifndef MGCMT_FUSED_MIN_ROWS
-#define MGCMT_FUSED_MIN_ROWS 4
-#endif
-constexpr long kFusedMinRows = MGCMT_FUSED_MIN_ROWS;  // shortest chunk: a wave's march has a fixed cost per row step
-
-template <class OP, int KIND, int NSWEEP, bool PROLONG, bool RESTRICT, bool ZERO_IN>
-void launch_one(hipStream_t s, FusedArgs a, int k) {
-  using Shape = FusedShape<OP, KIND, NSWEEP, PROLONG, RESTRICT>;
-  const long strips = (a.nc + Shape::wout - 1) / Shape::wout;
-  const long groups = (strips + kWavesPerBlock - 1) / kWavesPerBlock;
-  const long groups8 = (groups + 7) / 8 * 8;
-  a.n_col_groups = (int)groups;
-  // Rows per chunk.  Every wave does the same amount of work, so the best launch is ONE round: as many
-  // chunks as fit on the chip at this kernel's occupancy (a second, partly filled round costs a whole
-  // wave lifetime at low bandwidth), each as long as possible (long marches amortise the pipeline fill
-  // and the overlap rows).  The occupancy query can be one block per CU optimistic (MI355X_MICROARCH.md,
-  // "Residency"), hence the 10 % margin.
-  static int resident_blocks = 0;  // per instantiation: workgroups the chip holds at once
-  if (resident_blocks == 0) {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<OP, KIND, NSWEEP, PROLONG, RESTRICT, ZERO_IN>, 64 * kWavesPerBlock, 0) != hipSuccess ||
-        hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
-      resident_blocks = 768;
-    else
-      resident_blocks = per_cu * prop.multiProcessorCount;
-  }
-  long rows = g_fused_rows_override;
-  if (rows <= 0) {
-    long chunks = (long)(0.9 * resident_blocks) / (groups * k);
-    if (chunks < 1) chunks = 1;
-    rows = (a.nr + chunks - 1) / chunks;
-    if (rows < kFusedMinRows) rows = kFusedMinRows;
-  }
-  if (rows > a.nr) rows = a.nr;
-  rows = (rows + 1) & ~1L;
-  a.rows_per_chunk = (int)rows;
-  a.n_row_chunks = (int)((a.nr + rows - 1) / rows);
-  const unsigned blocks = (unsigned)(groups8 * a.n_row_chunks);
-  hipLaunchKernelGGL((k_fused<OP, KIND, NSWEEP, PROLONG, RESTRICT, ZERO_IN>), dim3(blocks, (unsigned)k), dim3(64 * kWavesPerBlock), 0, s, a);
-}
-
-template <class OP, int KIND, int NSWEEP>
-void launch_mode(hipStream_t s, const FusedArgs& a, int mode, int k) {
-  const bool zero_in = (mode & 4) != 0;
-  mode &= 3;
-  if (mode == 1) launch_one<OP, KIND, NSWEEP, true, false, false>(s, a, k);
-  else if (mode == 2) {
-    if (zero_in) launch_one<OP, KIND, NSWEEP, false, true, true>(s, a, k);
-    else launch_one<OP, KIND, NSWEEP, false, true, false>(s, a, k);
-  } else {
-    if (zero_in) launch_one<OP, KIND, NSWEEP, false, false, true>(s, a, k);
-    else launch_one<OP, KIND, NSWEEP, false, false, false>(s, a, k);
-  }
-}
-
 }  // namespace
+
+namespace fused {
+long fused_rows_override() { return g_fused_rows_override; }
+}  // namespace fused
 
 void fused_set_rows(long rows) { g_fused_rows_override = rows; }
 
@@ -547,11 +32,21 @@ bool fused_supported(const KGrid& g, const KOp& op) {
 // sweeps one pass can fuse: a 9-point four-colour sweep is already four pipeline stages
 int fused_max_sweeps(const KOp& op, int multicolour) { return (!op.five_point && multicolour) ? 1 : 2; }
 
-// One fused pass: vin -> vout with `nsweep` sweeps; mode & 3: 0 plain, 1 prolong+correct first (coarse
-// correction `coarse`), 2 residual+restriction last (coarse right-hand side `coarse`); mode & 4: vin is zero.
+// sweeps of pre-smoothing an up-leg pass with `nsweep` post-smoothing sweeps can recompute in front of the
+// correction (0: none): all stages plus the correction must fit the 8-column window overlap
+int fused_max_recompute(const KOp& op, int multicolour, int nsweep) {
+  if (!op.five_point && multicolour) return 0;                  // four-colour sweeps: four stages each
+  const int per_sweep = multicolour ? 2 : 1;
+  int n = (8 - 1 - per_sweep * nsweep) / per_sweep;
+  return n < 0 ? 0 : (n > 2 ? 2 : n);
+}
+
+// One fused pass: vin -> vout with `nsweep` sweeps.  mode & 3: 0 plain, 1 prolong+correct first (coarse = the
+// correction), 2 residual+restriction last (coarse = the coarse right-hand side); mode & 4: vin is zero;
+// mode & 8: vout is not written (mode 2 only); npre: pre-smoothing sweeps recomputed before the correction (mode 1).
 void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
-                  double omega, int multicolour, int nsweep, int mode, long row_lo, long row_hi, long last_row, int k) {
-  FusedArgs a{};
+                  double omega, int multicolour, int nsweep, int mode, int npre, long row_lo, long row_hi, long last_row, int k) {
+  fused::FusedArgs a{};
   a.vin = vin.p;
   a.f = f.p;
   a.vout = vout.p;
@@ -575,14 +70,9 @@ void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, K
   a.ldy = op.ldy;
   a.shifts = shifts;
   a.omega = omega;
+  const int flags = (mode & 15) | (npre << fused::kPreShift);
   if (op.five_point) {
-    if (multicolour) {
-      if (nsweep == 1) launch_mode<Op5, kRedBlack, 1>(s, a, mode, k);
-      else launch_mode<Op5, kRedBlack, 2>(s, a, mode, k);
-    } else {
-      if (nsweep == 1) launch_mode<Op5, kJacobi, 1>(s, a, mode, k);
-      else launch_mode<Op5, kJacobi, 2>(s, a, mode, k);
-    }
+    launch_fused_op5(s, a, multicolour, nsweep, flags, k);
   } else if (op.nine_const) {
     for (int i = 0; i < 3; ++i) {
       for (int j = 0; j < 3; ++j) a.c9[i][j] = op.c9[i][j];
@@ -591,19 +81,9 @@ void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, K
     }
     a.c9corner = op.c9corner;
     a.last_row = last_row;
-    if (multicolour) {
-      launch_mode<Op9c, kFourColour, 1>(s, a, mode, k);
-    } else {
-      if (nsweep == 1) launch_mode<Op9c, kJacobi, 1>(s, a, mode, k);
-      else launch_mode<Op9c, kJacobi, 2>(s, a, mode, k);
-    }
+    launch_fused_op9c(s, a, multicolour, nsweep, flags, k);
   } else {
-    if (multicolour) {
-      launch_mode<Op9<2>, kFourColour, 1>(s, a, mode, k);
-    } else {
-      if (nsweep == 1) launch_mode<Op9<2>, kJacobi, 1>(s, a, mode, k);
-      else launch_mode<Op9<2>, kJacobi, 2>(s, a, mode, k);
-    }
+    launch_fused_op9(s, a, multicolour, nsweep, flags, k);
   }
 }
 

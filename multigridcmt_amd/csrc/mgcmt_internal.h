@@ -56,14 +56,16 @@ void launch_prolong(hipStream_t s, KGrid fine, KGrid coarse, KVec e, KVec v, int
 void launch_lex_sweep(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta,
                       double wU, double wL, int k);
 
-// fused row-streaming passes (kernels_fused.hip): vin -> vout with nsweep sweeps of weighted Jacobi or
-// multicolour Gauss-Seidel; mode 0 plain, 1 prolong+correct first (coarse = correction), 2 residual+restrict
-// last (coarse = right-hand side)
+// fused row-streaming passes (fused_kernel.h, kernels_fused*.hip): vin -> vout with nsweep sweeps of weighted
+// Jacobi or multicolour Gauss-Seidel.  mode & 3: 0 plain, 1 prolong+correct first (coarse = correction), 2
+// residual+restrict last (coarse = right-hand side); mode & 4: vin is zero; mode & 8: vout is not written (mode 2);
+// npre: pre-smoothing sweeps recomputed in front of the correction (mode 1)
 bool fused_supported(const KGrid& g, const KOp& op);
 int fused_max_sweeps(const KOp& op, int multicolour);
+int fused_max_recompute(const KOp& op, int multicolour, int nsweep);
 void fused_set_rows(long rows);  // tuning: rows per chunk, 0 = automatic
 void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
-                  double omega, int multicolour, int nsweep, int mode, long row_lo, long row_hi, long last_row, int k);
+                  double omega, int multicolour, int nsweep, int mode, int npre, long row_lo, long row_hi, long last_row, int k);
 
 // vector algebra; scalar results / inputs live in device memory so nothing syncs with the host
 void launch_fill(hipStream_t s, double* p, long n, double value);
@@ -74,6 +76,9 @@ void launch_axpy(hipStream_t s, long n, double alpha, const double* x, double* y
 void launch_scale(hipStream_t s, long n, double alpha, double* x);
 // streaming probes: kind 0 copy (a -> out), 1 triad (a + s b -> out), 2 read-only (a)
 void launch_probe(hipStream_t s, int kind, long n, const double* a, const double* b, double* out, int blocks);
+// the fused kernels' access pattern alone (128-column windows marching down `rows` rows): kind 3 read 1 stream,
+// 4 read 2 streams, 5 read 2 + write 1; 6/7/8: the same with overlapping unaligned windows (124 of 128 columns kept)
+void launch_probe_march(hipStream_t s, long nr, long nc, long rows, int nstreams, int do_write, int wout, const double* a, const double* b, double* out);
 // out[q] = <x, y_q> for q < nq (y_q = y + q*ystride), deterministic two-pass reduction; `partials`
 // holds at least nq * reduce_blocks(n) doubles
 int reduce_blocks(long n);

@@ -132,6 +132,8 @@ struct mgcmt_plan {
   std::vector<double> h_shifts;
   bool has_mass = false;
   bool use_fused = true;
+  bool use_recompute = true;  // down-leg passes skip storing V', up-leg passes recompute it (fused_kernel.h)
+  bool force_recompute = false;  // ... on every fused level, not only the bandwidth-bound ones (tests)
   // HIP-graph replay of whole cycles (mgcmt_vcycle): the launch sequence of a cycle is fixed by its
   // parameters and by which of the two buffers of every level currently is "V", so it is captured once per
   // such state and replayed; small grids are launch-latency-bound otherwise.
@@ -143,6 +145,12 @@ struct mgcmt_plan {
   };
   std::map<std::string, CycleGraph> graphs;
   std::map<std::string, int> cycle_seen;
+  void graphs_invalidate() {  // a captured launch sequence is only valid for the options it was captured under
+    for (auto& g : graphs)
+      if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+    graphs.clear();
+    cycle_seen.clear();
+  }
 
   KGrid kgrid(int l) const {
     KGrid kg = levels[l].grid();
@@ -293,7 +301,7 @@ int post_launch() {
 // ---- smoothers --------------------------------------------------------------------------------
 
 // one fused row-streaming pass V -> T (then swapped) on a constant 5-point level
-int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, hipStream_t s) {
+int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, hipStream_t s, int npre = 0) {
   Level& L = p->levels[l];
   KVec coarse{nullptr, 0};
   long cnc = 0;
@@ -304,8 +312,8 @@ int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mod
   const long row_lo = L.r0 == 0 ? 0 : -kHalo;
   const long row_hi = L.r0 + L.nr == L.gr ? L.nr : L.nr + kHalo;
   launch_fused(s, p->kgrid(l), L.dA.k, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_T), coarse, cnc,
-               p->d_shifts, omega, kind == MGCMT_GS_MC ? 1 : 0, nsweep, mode, row_lo, row_hi, L.gr - 1 - L.r0, k);
-  std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
+               p->d_shifts, omega, kind == MGCMT_GS_MC ? 1 : 0, nsweep, mode, npre, row_lo, row_hi, L.gr - 1 - L.r0, k);
+  if (!(mode & 8)) std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);  // a no-store pass leaves V as it was
   return MGCMT_OK;
 }
 
@@ -431,7 +439,12 @@ int coarse_solve_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
 
 // pre-smoothing + residual + restriction (MGCMTSolver.py:313-316); one pass less on fused levels
 // zero_in: V[l] is known to be zero (and has not been cleared); true below the level the cycle starts on
-int down_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, bool zero_in, hipStream_t s) {
+// recompute (may be null): out — how many of the pre-smoothing sweeps were NOT stored (the residual was restricted
+// from them on the fly) and must be recomputed by up_leg from the untouched V; still_zero: V is still "zero, uncleared"
+int down_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, bool zero_in, hipStream_t s, int* recompute = nullptr,
+             bool* still_zero = nullptr, int nu_up = 0) {
+  if (recompute) *recompute = 0;
+  if (still_zero) *still_zero = false;
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
@@ -453,7 +466,17 @@ int down_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, bool z
       zi = 0;
       left -= n;
     }
-    MG_TRY(fused_pass(p, l, kind, left, omega, 2 | zi, k, s));
+    const int rmax = fused_max_recompute(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0, pass_sweeps(p, l, kind, nu_up));
+    // worth it where the level is bandwidth-bound; on small levels the longer pipeline of the up-leg pass costs more
+    // latency than the saved traffic is worth (measured: 1024^2 cycle 0.148 -> 0.179 ms with it)
+    const bool big = p->force_recompute || p->interior(l) >= (1L << 22);
+    if (recompute && p->use_recompute && big && left <= rmax) {
+      MG_TRY(fused_pass(p, l, kind, left, omega, 2 | 8 | zi, k, s));
+      *recompute = left;
+      if (still_zero) *still_zero = zi != 0;
+    } else {
+      MG_TRY(fused_pass(p, l, kind, left, omega, 2 | zi, k, s));
+    }
     return post_launch();
   }
   MG_TRY(smooth_impl(p, l, kind, nu, omega, k, s));
@@ -463,7 +486,7 @@ int down_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, bool z
 }
 
 // prolongation + correction + post-smoothing (MGCMTSolver.py:323-326)
-int up_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hipStream_t s) {
+int up_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hipStream_t s, int recompute = 0, bool still_zero = false) {
   if (nu >= 1 && fused_level(p, l, kind)) {
     MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
     MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
@@ -471,7 +494,7 @@ int up_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hipStrea
     MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
     int left = nu;
     const int first = pass_sweeps(p, l, kind, left);
-    MG_TRY(fused_pass(p, l, kind, first, omega, 1, k, s));
+    MG_TRY(fused_pass(p, l, kind, first, omega, 1 | (still_zero ? 4 : 0), k, s, recompute));
     left -= first;
     while (left > 0) {
       const int n = pass_sweeps(p, l, kind, left);
@@ -543,10 +566,18 @@ int ensure_coarse_factor(mgcmt_plan* p, int l, int k, hipStream_t s) {
 int vcycle_body(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k, int gram_schmidt,
                 hipStream_t s) {
   const int last = (int)p->levels.size() - 1;
-  for (int l = level; l < last; ++l) MG_TRY(down_leg(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, l > level, s));
+  std::vector<int> recompute(last + 1, 0);
+  std::vector<char> still_zero(last + 1, 0);
+  for (int l = level; l < last; ++l) {
+    const int nu_up = l == level ? nu2 : nu_coarse;
+    bool sz = false;
+    // the up-leg can only recompute the unstored sweeps if it runs a fused pass itself (>= 1 post-smoothing sweep)
+    MG_TRY(down_leg(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, l > level, s, nu_up >= 1 ? &recompute[l] : nullptr, &sz, nu_up));
+    still_zero[l] = sz;
+  }
   MG_TRY(coarse_solve_impl(p, last, k, s));
   for (int l = last - 1; l >= level; --l) {
-    MG_TRY(up_leg(p, l, kind, l == level ? nu2 : nu_coarse, omega, k, s));
+    MG_TRY(up_leg(p, l, kind, l == level ? nu2 : nu_coarse, omega, k, s, recompute[l], still_zero[l] != 0));
     if (gram_schmidt) MG_TRY(gramschmidt_impl(p, l, MGCMT_SLOT_V, k, 1, s));
   }
   return MGCMT_OK;
@@ -888,9 +919,10 @@ int mgcmt_twogrid(mgcmt_plan* p, int level, int nu1, int nu2, int kind, double o
   MG_TRY(check_k(p, k));
   if (level + 1 >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "twogrid needs a coarser level");
   hipStream_t s = S(stream);
-  MG_TRY(down_leg(p, level, kind, nu1, omega, k, false, s));
+  int recompute = 0;
+  MG_TRY(down_leg(p, level, kind, nu1, omega, k, false, s, nu2 >= 1 ? &recompute : nullptr, nullptr, nu2));
   MG_TRY(coarse_solve_impl(p, level + 1, k, s));
-  MG_TRY(up_leg(p, level, kind, nu2, omega, k, s));
+  MG_TRY(up_leg(p, level, kind, nu2, omega, k, s, recompute));
   return MGCMT_OK;
 }
 
@@ -976,7 +1008,10 @@ int mgcmt_fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, i
   MG_TRY(check_level(p, l));
   MG_TRY(check_k(p, k));
   if (!fused_level(p, l, kind)) return fail(MGCMT_ERR_UNSUPPORTED, "level / smoother not covered by the fused kernels");
-  if (nsweep < 1 || nsweep > pass_sweeps(p, l, kind, nsweep) || mode < 0 || mode > 6 || (mode & 3) == 3 || mode == 5)
+  const int transfer = mode & 3, npre = (mode >> 4) & 3;
+  if (nsweep < 1 || nsweep > pass_sweeps(p, l, kind, nsweep) || mode < 0 || mode > 63 || transfer == 3 || ((mode & 8) && transfer != 2) ||
+      (npre && transfer != 1) || npre > fused_max_recompute(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0, nsweep) ||
+      (transfer == 1 && (mode & 4) && !npre))
     return fail(MGCMT_ERR_INVALID, "bad nsweep or mode");
   if ((mode & 3) != 0 && l + 1 >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "no coarser level");
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
@@ -986,7 +1021,7 @@ int mgcmt_fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, i
     MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
     MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_F));
   }
-  MG_TRY(fused_pass(p, l, kind, nsweep, omega, mode, k, S(stream)));
+  MG_TRY(fused_pass(p, l, kind, nsweep, omega, mode & 15, k, S(stream), npre));
   return post_launch();
 }
 
@@ -1001,6 +1036,13 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
   if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
   if (option == MGCMT_OPT_FUSED) {
     p->use_fused = value != 0;
+    p->graphs_invalidate();
+    return MGCMT_OK;
+  }
+  if (option == MGCMT_OPT_RECOMPUTE) {
+    p->use_recompute = value != 0;
+    p->force_recompute = value == 2;
+    p->graphs_invalidate();
     return MGCMT_OK;
   }
   if (option == MGCMT_OPT_GRAPH) {
@@ -1034,7 +1076,7 @@ int mgcmt_time_smoother(mgcmt_plan* p, int l, int kind, int nu, double omega, in
 
 int mgcmt_bandwidth_probe(mgcmt_plan* p, int l, int kind, int blocks, int reps, double* ms_out, void* stream) {
   MG_TRY(check_level(p, l));
-  if (!ms_out || reps < 1 || blocks < 1 || kind < 0 || kind > 2) return fail(MGCMT_ERR_INVALID, "bad arguments");
+  if (!ms_out || reps < 1 || blocks < 1 || kind < 0 || kind > 8) return fail(MGCMT_ERR_INVALID, "bad arguments");
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
@@ -1042,10 +1084,16 @@ int mgcmt_bandwidth_probe(mgcmt_plan* p, int l, int kind, int blocks, int reps, 
   hipEvent_t a, b;
   MG_HIP(hipEventCreate(&a));
   MG_HIP(hipEventCreate(&b));
-  launch_probe(S(stream), kind, n, p->kvec(l, MGCMT_SLOT_V).p, p->kvec(l, MGCMT_SLOT_F).p, p->kvec(l, MGCMT_SLOT_T).p, blocks);
+  auto go = [&]() {
+    if (kind <= 2) launch_probe(S(stream), kind, n, p->kvec(l, MGCMT_SLOT_V).p, p->kvec(l, MGCMT_SLOT_F).p, p->kvec(l, MGCMT_SLOT_T).p, blocks);
+    else  // marching pattern: `blocks` = rows per chunk
+      launch_probe_march(S(stream), p->levels[l].nr, p->levels[l].gc, blocks, (kind == 3 || kind == 6) ? 1 : 2, (kind == 5 || kind == 8) ? 1 : 0,
+                         kind >= 6 ? 124 : 128, p->kvec(l, MGCMT_SLOT_V).p,
+                         p->kvec(l, MGCMT_SLOT_F).p, p->kvec(l, MGCMT_SLOT_T).p);
+  };
+  go();
   MG_HIP(hipEventRecord(a, S(stream)));
-  for (int r = 0; r < reps; ++r)
-    launch_probe(S(stream), kind, n, p->kvec(l, MGCMT_SLOT_V).p, p->kvec(l, MGCMT_SLOT_F).p, p->kvec(l, MGCMT_SLOT_T).p, blocks);
+  for (int r = 0; r < reps; ++r) go();
   MG_HIP(hipEventRecord(b, S(stream)));
   MG_HIP(hipEventSynchronize(b));
   float ms = 0.f;

@@ -136,3 +136,26 @@ def test_fused_general_separable_operator(backend, kind, omega):
     x = p.download(0, _lib.SLOT_V, 0)
     p.close()
     assert rel_err(x, y) < 1e-10
+
+
+@pytest.mark.parametrize("kind,omega", [(_lib.WJACOBI, 2. / 3.), (_lib.GS_MC, 1.0)])
+def test_recompute_instead_of_store_is_exact(backend, kind, omega):
+    """MGCMT_OPT_RECOMPUTE: the down-leg pass skips storing the pre-smoothed iterate and the up-leg pass re-runs the
+    same sweeps before adding the correction — the same arithmetic, so the cycle's result is bit-identical."""
+    g = 256
+    op = laplacian_operator(g, "2d") * SCALE
+    rng = np.random.RandomState(21)
+    v0, f = rng.rand(g * g), rng.rand(g * g)
+    for nu1, nu2, nuc in ((2, 2, 2), (1, 2, 4), (3, 1, 2), (4, 4, 4)):
+        outs = []
+        for rec in (2, 0):                                  # 2 = on every fused level (default: only large ones)
+            p = Plan(op, 8, nvec=1)
+            p.set_option(_lib.OPT_RECOMPUTE, rec)
+            p.set_shifts([0.6])
+            p.upload(0, _lib.SLOT_V, 0, v0)
+            p.upload(0, _lib.SLOT_F, 0, f)
+            for _ in range(2):
+                p.vcycle(nu1, nu2, kind, omega=omega, nu_coarse=nuc)
+            outs.append(p.download(0, _lib.SLOT_V, 0))
+            p.close()
+        assert np.array_equal(outs[0], outs[1]), (nu1, nu2, nuc)
