@@ -260,12 +260,22 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   constexpr int WN = NINE ? S + E : 1;  // windows that also keep the lateral neighbours
   constexpr int D = NINE ? kDepth9 : kDepth;  // rows per prefetch batch
 
-  // workgroup -> (column group, row chunk): blocks b and b+8 run on the same XCD, so one XCD walks
-  // down the chunks of one column group and the overlapping rows are re-read from its own L2
+  // workgroup -> (column group, row chunk).  Blocks b and b+8 run on the same XCD (own L2): an XCD gets a
+  // CONTIGUOUS range of column groups, so the half cache lines two neighbouring windows share (their 8-column
+  // overlap is 64 bytes on each side) and the overlap rows of vertically adjacent chunks come from that L2.
+#ifdef MGCMT_FUSED_XCD_INTERLEAVED
   const int b = blockIdx.x;
   const int xcd = b & 7, seq = b >> 3;
   const int chunk = seq % a.n_row_chunks;
   const int group = xcd + 8 * (seq / a.n_row_chunks);
+#else
+  const int b = blockIdx.x;
+  const int xcd = b & 7, seq = b >> 3;
+  const int per_xcd = (a.n_col_groups + 7) >> 3;
+  const int group = xcd * per_xcd + seq % per_xcd;
+  const int chunk = seq / per_xcd;
+  if (seq % per_xcd + xcd * per_xcd >= a.n_col_groups || chunk >= a.n_row_chunks) return;
+#endif
   if (group >= a.n_col_groups) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long strip = (long)group * kWavesPerBlock + wave;
