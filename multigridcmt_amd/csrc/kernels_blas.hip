@@ -74,6 +74,29 @@ __global__ void __launch_bounds__(kRedThreads) k_dot_final(int nblocks, const do
   if (threadIdx.x == 0) out[q] = t;
 }
 
+// sum of one result's per-block partial sums, in index order, by every thread that needs it (<= 1024 terms)
+__device__ __forceinline__ double sum_partials(const double* __restrict__ partials, int nblocks) {
+  double t = 0.0;
+  for (int i = 0; i < nblocks; ++i) t += partials[i];
+  return t;
+}
+
+// x /= sqrt(sum of partials)  — the second pass of a norm folded into the scaling (MGCMTProcessor.py:45)
+__global__ void k_scale_by_norm(long n, const double* __restrict__ partials, int nblocks, double* __restrict__ x) {
+  const double d = sqrt(sum_partials(partials, nblocks));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = x[i] / d;
+}
+
+// a_j -= (<a_j,q> / <q,q>) q for j = 1..nj (blockIdx.y = j-1); result 0 of the partial sums is <q,q>, result j is
+// <q,a_j> (MGCMTProcessor.py:17-20,48-50).  One launch instead of one axpy per column.
+__global__ void k_project_out(long n, const double* __restrict__ partials, int nblocks, const double* __restrict__ q, double* __restrict__ a,
+                              long astride) {
+  const int j = blockIdx.y + 1;
+  const double c = sum_partials(partials + (long)j * nblocks, nblocks) / sum_partials(partials, nblocks);
+  double* aj = a + (long)(j - 1) * astride;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) aj[i] -= c * q[i];
+}
+
 // bandwidth probes (bench.py's empirical HBM ceilings): 16-byte accesses, grid-stride
 __global__ void k_probe_copy(long n2, const double2* __restrict__ a, double2* __restrict__ out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) out[i] = a[i];
@@ -170,6 +193,19 @@ int reduce_blocks(long n) {
   if (b > kRedMaxBlocks) b = kRedMaxBlocks;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+// first pass only: partials[q*reduce_blocks(n) + b]
+void launch_dot_partials(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials) {
+  hipLaunchKernelGGL(k_dot_partial, dim3(reduce_blocks(n), nq), dim3(kRedThreads), 0, s, n, x, y, ystride, partials);
+}
+
+void launch_scale_by_norm(hipStream_t s, long n, const double* partials, double* x) {
+  hipLaunchKernelGGL(k_scale_by_norm, dim3(blocks_for(n)), dim3(256), 0, s, n, partials, reduce_blocks(n), x);
+}
+
+void launch_project_out(hipStream_t s, long n, const double* partials, const double* q, double* a_first, long astride, int nj) {
+  hipLaunchKernelGGL(k_project_out, dim3(blocks_for(n), nj), dim3(256), 0, s, n, partials, reduce_blocks(n), q, a_first, astride);
 }
 
 void launch_dots(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, double* out) {

@@ -83,6 +83,11 @@ void launch_probe_march(hipStream_t s, long nr, long nc, long rows, int nstreams
 // holds at least nq * reduce_blocks(n) doubles
 int reduce_blocks(long n);
 void launch_dots(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, double* out);
+// Gram-Schmidt building blocks that consume the first reduction pass directly (no separate final pass / no scalar
+// round trip): x /= sqrt(sum partials);  a_j -= (<q,a_j>/<q,q>) q for nj columns in one launch
+void launch_dot_partials(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials);
+void launch_scale_by_norm(hipStream_t s, long n, const double* partials, double* x);
+void launch_project_out(hipStream_t s, long n, const double* partials, const double* q, double* a_first, long astride, int nj);
 
 // banded LU of (A - mu I) on the coarsest level and its solves (one workgroup per vector)
 struct KBand {

@@ -517,16 +517,18 @@ int gramschmidt_impl(mgcmt_plan* p, int l, int slot, int k, int modified, hipStr
   double* sc = p->d_scalars;
   if (modified) {
     // MGCMTProcessor.py:44-50: q_i = a_i/|a_i|; a_j -= (<a_j,q_i>/<q_i,q_i>) q_i for j > i
+    // four launches per column: norm partials, scale, <q_i, .> partials for all later columns, projection of all of them
     for (int i = 0; i < k; ++i) {
       double* ai = a0 + i * stride;
-      launch_dots(s, n, ai, ai, 0, 1, p->d_partials, sc);
-      launch_scale_dev(s, n, sc, 1, ai);
+      launch_dot_partials(s, n, ai, ai, 0, 1, p->d_partials);
+      launch_scale_by_norm(s, n, p->d_partials, ai);
       if (i + 1 < k) {
-        // sc[0] = <q_i,q_i>, sc[1+t] = <q_i, a_{i+1+t}>
-        launch_dots(s, n, ai, ai, stride, k - i, p->d_partials, sc);
-        for (int j = i + 1; j < k; ++j) launch_axpy_dev(s, n, sc + (j - i), sc, -1.0, ai, a0 + j * stride);
+        // result 0 = <q_i,q_i>, result t = <q_i, a_{i+t}>
+        launch_dot_partials(s, n, ai, ai, stride, k - i, p->d_partials);
+        launch_project_out(s, n, p->d_partials, ai, ai + stride, stride, k - i - 1);
       }
     }
+    (void)sc;
   } else {
     // MGCMTProcessor.py:34-42: u_j = a_j - sum_{i<j} (<a_j,u_i>/<u_i,u_i>) u_i with the ORIGINAL a_j in every
     // inner product, then all columns normalised
@@ -998,8 +1000,8 @@ int mgcmt_normalize(mgcmt_plan* p, int l, int slot, int k, void* stream) {
   MG_TRY(ensure_slot(p, l, slot));
   for (int i = 0; i < k; ++i) {
     double* a = p->kvec(l, slot, i).p;
-    launch_dots(S(stream), p->interior(l), a, a, 0, 1, p->d_partials, p->d_scalars);
-    launch_scale_dev(S(stream), p->interior(l), p->d_scalars, 1, a);
+    launch_dot_partials(S(stream), p->interior(l), a, a, 0, 1, p->d_partials);
+    launch_scale_by_norm(S(stream), p->interior(l), p->d_partials, a);
   }
   return post_launch();
 }
