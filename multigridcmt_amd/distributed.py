@@ -128,11 +128,12 @@ class ShardedPlan:
         rows = self.plan.shapes[level][0]
         if self.rank == 0:
             self.rows_view(self.coarse, 0, dst_slot, 0, rows).copy_(self.rows_view(self.plan, level, slot, 0, rows))
-            works = [dist.irecv(self.rows_view(self.coarse, 0, dst_slot, r * rows, rows), r) for r in range(1, self.world)]
-            for w in works:
-                w.wait()
+            ops = [dist.P2POp(dist.irecv, self.rows_view(self.coarse, 0, dst_slot, r * rows, rows), r) for r in range(1, self.world)]
         else:
-            dist.send(self.rows_view(self.plan, level, slot, 0, rows), 0)
+            ops = [dist.P2POp(dist.isend, self.rows_view(self.plan, level, slot, 0, rows), 0)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
 
     def scatter_from_root(self, level, slot, src_slot):
         """Rank 0's whole-grid vector -> strips of (level, slot) including the halo rows that exist."""
@@ -146,15 +147,16 @@ class ShardedPlan:
         if self.rank == 0:
             lo, hi = span(0)
             self.rows_view(self.plan, level, slot, lo, hi - lo).copy_(self.rows_view(self.coarse, 0, src_slot, lo, hi - lo))
-            works = []
+            ops = []
             for r in range(1, self.world):
                 lo, hi = span(r)
-                works.append(dist.isend(self.rows_view(self.coarse, 0, src_slot, lo, hi - lo), r))
-            for w in works:
-                w.wait()
+                ops.append(dist.P2POp(dist.isend, self.rows_view(self.coarse, 0, src_slot, lo, hi - lo), r))
         else:
             lo, hi = span(self.rank)
-            dist.recv(self.rows_view(self.plan, level, slot, lo - self.rank * rows, hi - lo), 0)
+            ops = [dist.P2POp(dist.irecv, self.rows_view(self.plan, level, slot, lo - self.rank * rows, hi - lo), 0)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
 
     # -- data ---------------------------------------------------------------------------------------
     def set_shift(self, mu):

@@ -2,4 +2,4 @@ set -e
 cd "$(dirname "$0")/../multigridcmt_amd/csrc"
 rm -rf ../../build/variants; mkdir -p ../../build/variants
 build() { name=$1; shift; make -s -j8 OUT=$PWD/../../build/variants/lib_$name.so OBJDIR=$PWD/../../build/variants/obj_$name "$@"; echo built $name; }
-build xcd_interleaved EXTRA=-DMGCMT_FUSED_XCD_INTERLEAVED=1
+build fma FUSED_FLAGS=-ffp-contract=fast
