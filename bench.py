@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--lowest", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
     return ap.parse_args()
 
 
@@ -72,7 +73,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1:
+    if args.gpus > 1 or args.force_sharded:
         from multigridcmt_amd import dist_bench
         return dist_bench.run(args)
 

@@ -14,8 +14,9 @@ def run(args):
     from .distributed import ShardedPlan
     from .operators import laplacian_operator
 
-    rank = int(os.environ["RANK"])
-    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_PORT", "29533")
     local = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local)
