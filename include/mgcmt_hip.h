@@ -152,6 +152,8 @@ int mgcmt_normalize(mgcmt_plan* plan, int level, int slot, int k, void* stream);
  * level (0 = the level is not covered by the fused kernels). */
 int mgcmt_fused_pass(mgcmt_plan* plan, int level, int kind, int nsweep, double omega, int mode, int k, void* stream);
 int mgcmt_fused_max_sweeps(const mgcmt_plan* plan, int level, int kind, int* max_sweeps);
+/* how many pre-smoothing sweeps a mode-1 pass with `nsweep` post-smoothing sweeps can recompute on that level */
+int mgcmt_fused_max_recompute(const mgcmt_plan* plan, int level, int kind, int nsweep, int* max_recompute);
 
 /* plan options: MGCMT_OPT_FUSED (default 1) selects the fused row-streaming kernels on large constant-
  * coefficient levels; 0 forces the one-launch-per-operation kernels everywhere (A/B checks) */

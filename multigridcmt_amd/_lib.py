@@ -74,6 +74,7 @@ _SIGNATURES = {
     "mgcmt_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "mgcmt_fused_pass": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p]),
     "mgcmt_fused_max_sweeps": (c_int, [c_void_p, c_int, c_int, POINTER(c_int)]),
+    "mgcmt_fused_max_recompute": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int)]),
     "mgcmt_plan_set_option": (c_int, [c_void_p, c_int, c_int]),
     "mgcmt_bandwidth_probe": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _dp, c_void_p]),
     "mgcmt_time_smoother": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, _dp, c_void_p]),

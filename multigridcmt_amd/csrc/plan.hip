@@ -1034,6 +1034,13 @@ int mgcmt_fused_max_sweeps(const mgcmt_plan* p, int l, int kind, int* max_sweeps
   return MGCMT_OK;
 }
 
+int mgcmt_fused_max_recompute(const mgcmt_plan* p, int l, int kind, int nsweep, int* max_recompute) {
+  MG_TRY(check_level(p, l));
+  if (!max_recompute) return fail(MGCMT_ERR_INVALID, "null output");
+  *max_recompute = fused_level(p, l, kind) ? fused_max_recompute(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0, nsweep) : 0;
+  return MGCMT_OK;
+}
+
 int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
   if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
   if (option == MGCMT_OPT_FUSED) {

@@ -20,7 +20,7 @@ def run(args):
     local = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     g = args.grid
     kind = _lib.WJACOBI if args.smoother == "wjacobi" else _lib.GS_MC
     omega = 2.0 / 3.0 if args.smoother == "wjacobi" else 1.0

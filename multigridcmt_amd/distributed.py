@@ -78,6 +78,8 @@ class ShardedPlan:
             self.coarse = Plan(StructuredOperator("2d", self.switch, terms), lowest, nvec=1, device=device)
         self._views = {}
         self._fine_rhs_halo_valid = False
+        self.use_recompute = True
+        self.recompute_min_points = 1 << 22          # per-rank level size from which recomputing beats storing
 
     # -- zero-copy tensor views of plan memory ------------------------------------------------------
     def _flat(self, plan, level, slot):
@@ -196,10 +198,14 @@ class ShardedPlan:
             raise ValueError("the sharded cycle needs at least one pre- and one post-smoothing sweep")
         nu_coarse = nu1 if nu_coarse is None else nu_coarse
         P, ls = self.plan, self.strip_levels
+        recompute, still_zero = [0] * ls, [False] * ls
         for l in range(ls):
-            nu = nu1 if l == 0 else nu_coarse
+            nu, nu_up = (nu1, nu2) if l == 0 else (nu_coarse, nu_coarse)
             passes = self._passes(l, kind, nu)
+            first_up = self._passes(l, kind, nu_up)[0]
             for i, n in enumerate(passes):
+                last = i == len(passes) - 1
+                zero_in = i == 0 and l > 0                 # the coarse iterate starts at zero: nothing to read or exchange
                 if i == 0 and l == 0:
                     # F of the fine level is constant between uploads: its halo rows travel once
                     if self._fine_rhs_halo_valid:
@@ -208,26 +214,34 @@ class ShardedPlan:
                         self.exchange_halo((0, SLOT_V), (0, SLOT_F))
                         self._fine_rhs_halo_valid = True
                 elif i == 0:
-                    self.exchange_halo((l, SLOT_F))        # V[l] starts at zero: nothing to exchange, nothing to read
+                    self.exchange_halo((l, SLOT_F))
                 else:
                     self.exchange_halo((l, SLOT_V))
-                mode = (2 if i == len(passes) - 1 else 0) | (4 if (i == 0 and l > 0) else 0)
-                P.fused_pass(l, kind, n, omega=omega, mode=mode)
+                mode = 2 if last else 0
+                # recompute instead of store (bandwidth-bound levels): the last down-leg pass writes only the
+                # restricted residual, the first up-leg pass re-runs its sweeps from the untouched V
+                if last and self.use_recompute and P.size(l) >= self.recompute_min_points and n <= P.fused_max_recompute(l, kind, first_up):
+                    mode |= 8
+                    recompute[l], still_zero[l] = n, zero_in
+                P.fused_pass(l, kind, n, omega=omega, mode=mode | (4 if zero_in else 0))
         # the coarse problem: gather, run the sub-cycle on rank 0, scatter the correction with its halo rows
         self.gather_to_root(ls, SLOT_F, SLOT_F)
         if self.rank == 0:
-            self.coarse.fill(0, SLOT_V, 0, 0.0)
-            self.coarse.vcycle(nu_coarse, nu_coarse, kind, omega=omega, k=1, nu_coarse=nu_coarse)
+            self.coarse.vcycle(nu_coarse, nu_coarse, kind, omega=omega, k=1, nu_coarse=nu_coarse, level=0, zero_start=True)
         self.scatter_from_root(ls, SLOT_V, SLOT_V)
         for l in range(ls - 1, -1, -1):
             nu = nu2 if l == 0 else nu_coarse
             passes = self._passes(l, kind, nu)
             for i, n in enumerate(passes):
+                need = []
                 if i == 0 and l + 1 < ls:
-                    self.exchange_halo((l, SLOT_V), (l + 1, SLOT_V))   # iterate + the correction to interpolate
-                else:
-                    self.exchange_halo((l, SLOT_V))
-                P.fused_pass(l, kind, n, omega=omega, mode=1 if i == 0 else 0)
+                    need.append((l + 1, SLOT_V))           # the correction to interpolate
+                if not (i == 0 and recompute[l]):
+                    need.append((l, SLOT_V))               # (a recomputing pass reads the V whose halo rows are still valid)
+                if need:
+                    self.exchange_halo(*need)
+                mode = (1 | (4 if still_zero[l] else 0) | (recompute[l] << 4)) if i == 0 else 0
+                P.fused_pass(l, kind, n, omega=omega, mode=mode)
 
     def residual_norm(self):
         """|| F - (A - mu I) V ||_2 over all ranks."""

@@ -125,7 +125,12 @@ class Plan:
     def coarse_solve(self, level, k=1, stream=None):
         check(_lib.lib().mgcmt_coarse_solve(self._h, level, k, stream))
 
-    def vcycle(self, nu1, nu2, kind, omega=1.0, k=1, nu_coarse=4, gram_schmidt=False, level=0, stream=None):
+    def vcycle(self, nu1, nu2, kind, omega=1.0, k=1, nu_coarse=4, gram_schmidt=False, level=0, stream=None, zero_start=False):
+        """zero_start: the iterate on `level` is to be taken as zero (it is cleared first; the sharded driver's
+        root sub-cycle starts this way)."""
+        if zero_start:
+            for q in range(k):
+                self.fill(level, SLOT_V, q, 0.0, stream)
         check(_lib.lib().mgcmt_vcycle(self._h, level, nu1, nu2, nu_coarse, kind, c_double(omega), k,
                                       1 if gram_schmidt else 0, stream))
 
@@ -164,6 +169,11 @@ class Plan:
     def fused_max_sweeps(self, level, kind):
         n = c_int(0)
         check(_lib.lib().mgcmt_fused_max_sweeps(self._h, level, kind, ctypes.byref(n)))
+        return n.value
+
+    def fused_max_recompute(self, level, kind, nsweep):
+        n = c_int(0)
+        check(_lib.lib().mgcmt_fused_max_recompute(self._h, level, kind, nsweep, ctypes.byref(n)))
         return n.value
 
     def set_option(self, option, value):

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, g, kind, omega, nu, out_dir):
+def _worker(rank, world, port, g, kind, omega, nu, out_dir, force_recompute):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hip_cpu_mock")):
@@ -34,6 +34,8 @@ def _worker(rank, world, port, g, kind, omega, nu, out_dir):
     op = laplacian_operator(g, "2d") * (-1 / np.pi ** 2)
     sp = ShardedPlan(op, 8, rank, world, switch_grid=g // 4, on_gpu=False)
     sp.set_shift(0.4)
+    if force_recompute:
+        sp.recompute_min_points = 0                 # take the recompute-instead-of-store passes on these small strips too
     rng = np.random.RandomState(5)
     f, v0 = rng.rand(g * g), rng.rand(g * g)
     rows = g // world
@@ -50,9 +52,9 @@ def _worker(rank, world, port, g, kind, omega, nu, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world,force_recompute", [(2, False), (4, False), (2, True)])
 @pytest.mark.parametrize("kind_name", ["wjacobi", "rb"])
-def test_sharded_cycle_equals_single_plan(tmp_path, world, kind_name):
+def test_sharded_cycle_equals_single_plan(tmp_path, world, kind_name, force_recompute):
     import torch.multiprocessing as mp
     from conftest import bind_backend
     bind_backend("emu")
@@ -61,7 +63,7 @@ def test_sharded_cycle_equals_single_plan(tmp_path, world, kind_name):
     from multigridcmt_amd.plan import Plan
     g, nu = 1024, 2
     kind, omega = (_lib.WJACOBI, 2. / 3.) if kind_name == "wjacobi" else (_lib.GS_MC, 1.0)
-    mp.spawn(_worker, args=(world, _free_port(), g, kind, omega, nu, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), g, kind, omega, nu, str(tmp_path), force_recompute), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / ("part%d.npy" % r)) for r in range(world)])
     res, strip_levels = np.load(tmp_path / "res.npy")
     assert strip_levels == 2
