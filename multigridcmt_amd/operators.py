@@ -15,15 +15,6 @@ import numpy as np
 import scipy.sparse as sp
 
 
-def tri(lo, di, up):
-    """Three arrays of length n (lo[0] and up[n-1] ignored -> 0) as one (3, n) float64 block."""
-    t = np.zeros((3, len(di)), dtype=np.float64)
-    t[0, 1:] = np.asarray(lo, dtype=np.float64)[1:] if len(lo) == len(di) else np.asarray(lo, dtype=np.float64)
-    t[1] = di
-    t[2, :-1] = np.asarray(up, dtype=np.float64)[:-1] if len(up) == len(di) else np.asarray(up, dtype=np.float64)
-    return t
-
-
 def tri_identity(n):
     t = np.zeros((3, n))
     t[1] = 1.0
