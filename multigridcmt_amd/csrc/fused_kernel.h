@@ -122,7 +122,9 @@ struct Op5 {
     cn = a.cn;
     cw = a.cw;
   }
-  __device__ __forceinline__ void set_row(const FusedArgs&, long) {}
+  static constexpr int kRowValues = 0;  // per-row operator data staged through LDS (none)
+  __device__ __forceinline__ double fetch_row(const FusedArgs&, long, int) const { return 0.0; }
+  __device__ __forceinline__ void set_row(const FusedArgs&, long, const double*) {}
   template <int COL>
   __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
     off = fma(cn, n[1] + s[1], cw * (c[0] + c[2]));
@@ -163,7 +165,9 @@ struct Op9c {
     ic = i01 - i00;
     irc = i11 - i10 - i01 + i00;
   }
-  __device__ __forceinline__ void set_row(const FusedArgs&, long row) { lr = row == last_row_index ? 1.0 : 0.0; }
+  static constexpr int kRowValues = 0;
+  __device__ __forceinline__ double fetch_row(const FusedArgs&, long, int) const { return 0.0; }
+  __device__ __forceinline__ void set_row(const FusedArgs&, long row, const double*) { lr = row == last_row_index ? 1.0 : 0.0; }
   template <int COL>
   __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
     const double lc = COL == 1 ? lastb : 0.0;
@@ -176,11 +180,15 @@ struct Op9c {
   }
 };
 
-// general separable 9-point operator  sum_m X_m (x) Y_m : the lane keeps the column factors of its two
-// columns in registers; the row factors of the current row are wave-uniform scalar loads
+// general separable 9-point operator  sum_m X_m (x) Y_m  (variable coefficients: potentials, PotWellSolver.py:150-153
+// style wells): the lane keeps the column factors of its two columns in registers.  The row factors (3M numbers per
+// row, the same for every lane) travel with the prefetched rows — lane k < 3M loads value k of the row — and are
+// parked in a small LDS ring indexed by the row, from which every stage reads the row it is updating (LDS reads are
+// counted by lgkmcnt, so they never stall the vmcnt-ordered stream of row loads).
 template <int M>
 struct Op9 {
   static constexpr bool kNine = true;
+  static constexpr int kRowValues = 3 * M;
   double mu;
   double ya[M][3], yb[M][3];  // lower, diag, upper of Y_m at columns ja, ja+1
   double x[M][3];             // lower, diag, upper of X_m at the row being updated
@@ -195,12 +203,16 @@ struct Op9 {
         yb[m][p] = a.Y[m][p * a.ldy + j + 1];
       }
   }
-  __device__ __forceinline__ void set_row(const FusedArgs& a, long row) {
-    const long r = row < a.row_lo ? a.row_lo : (row >= a.row_hi ? a.row_hi - 1 : row);
+  // value `lane` (= 3*m + part) of row `rl` (already clamped into the allocation)
+  __device__ __forceinline__ double fetch_row(const FusedArgs& a, long rl, int lane) const {
+    const int k = lane < 3 * M ? lane : 3 * M - 1;
+    return a.X[k / 3][(k % 3) * a.ldx + rl];
+  }
+  __device__ __forceinline__ void set_row(const FusedArgs&, long, const double* ring_row) {
 #pragma unroll
     for (int m = 0; m < M; ++m)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) x[m][p] = a.X[m][p * a.ldx + r];
+      for (int p = 0; p < 3; ++p) x[m][p] = ring_row[3 * m + p];
   }
   template <int COL>
   __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
@@ -322,7 +334,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   struct Row {
     double2 v, f;
     double e;
+    double xr;  // one of the row's operator values (policies with kRowValues > 0)
   };
+  constexpr int RV = OP::kRowValues;
+  constexpr int kRing = 16;  // rows of operator values kept in LDS; a stage lags at most S + E + 1 <= 10 rows
+  __shared__ double s_ring[kWavesPerBlock][RV > 0 ? kRing * RV : 1];
+  double* ring = s_ring[wave];
   Row setA[D], setB[D];
   auto fetch = [&](long row, Row& r) __attribute__((always_inline)) {
     const long rl = row < a.row_lo ? a.row_lo : (row >= a.row_hi ? a.row_hi - 1 : row);
@@ -334,6 +351,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
       const long I = rl >> 1;
       r.e = ec[(I < crow_lo ? crow_lo : (I > crow_hi ? crow_hi : I)) * a.cnc + jc_ld];
     }
+    r.xr = RV > 0 ? op.fetch_row(a, rl, lane) : 0.0;
   };
 #pragma unroll
   for (int u = 0; u < D; ++u) fetch(rstart + u, setA[u]);
@@ -405,6 +423,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
 
   // one marching step: consume the prefetched row `row`, run every stage one row further
   auto step = [&](const long row, const Row& in) __attribute__((always_inline)) {
+    if (RV > 0 && lane < RV) ring[(row & (kRing - 1)) * RV + lane] = in.xr;  // this row's operator values
     const bool in_dom = col_in && row_ok(row);
     double ina = in_dom ? in.v.x : 0.0, inb = in_dom ? in.v.y : 0.0;
     const double fna = in_dom ? in.f.x : 0.0, fnb = in_dom ? in.f.y : 0.0;
@@ -462,7 +481,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
       }
       double na = ca, nb = cb;
       if (upd_a || upd_b) {  // wave-uniform
-        op.set_row(a, rs);
+        op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
         if (upd_a) {
           double off, dg, inv;
           eval_a(s, off, dg, inv);
@@ -486,7 +505,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
       push(S, oa, ob);
       const long rr = row - (S + 1);  // residual row completed now
       const double ca = wa[S][1], cb = wb[S][1];
-      op.set_row(a, rr);
+      op.set_row(a, rr, ring + (rr & (kRing - 1)) * RV);
       double offa, offb, dga, dgb, inva, invb;
       eval_a(S, offa, dga, inva);
       eval_b(S, offb, dgb, invb);
@@ -601,6 +620,7 @@ void launch_variant(hipStream_t s, const FusedArgs& a, int flags, int k) {
 // per-policy entry points (one translation unit each: kernels_fused_op5.hip, _op9c.hip, _op9.hip)
 void launch_fused_op5(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);
 void launch_fused_op9c(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);
-void launch_fused_op9(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);
+void launch_fused_op9(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);    // two terms
+void launch_fused_op9m3(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);  // three terms
 
 }  // namespace mgcmt

@@ -22,11 +22,11 @@ void fused_set_rows(long rows) { g_fused_rows_override = rows; }
 #endif
 constexpr long kFusedMinCols = MGCMT_FUSED_MIN_COLS;
 
-// Levels the fused kernels cover: 2-D, constant 5-point or two-term separable 9-point operators (the
-// scaled Laplacian and all its Galerkin coarsenings).  Narrow levels run too (one partly filled wave per
+// Levels the fused kernels cover: 2-D, constant 5-point operators, their Galerkin coarsenings, and general
+// separable operators of two or three Kronecker terms (Laplacian plus potential).  Narrow levels run too (one partly filled wave per
 // chunk): a fused pass there replaces four to nine tiny launches, which is what small levels cost.
 bool fused_supported(const KGrid& g, const KOp& op) {
-  return g.coarsen_rows && g.nr >= 4 && g.nc >= kFusedMinCols && (g.nc & 1) == 0 && (g.nr & 1) == 0 && (op.five_point || op.nine_const || op.nterms == 2);
+  return g.coarsen_rows && g.nr >= 4 && g.nc >= kFusedMinCols && (g.nc & 1) == 0 && (g.nr & 1) == 0 && (op.five_point || op.nine_const || op.nterms == 2 || op.nterms == 3);
 }
 
 // sweeps one pass can fuse: a 9-point four-colour sweep is already four pipeline stages
@@ -82,6 +82,8 @@ void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, K
     a.c9corner = op.c9corner;
     a.last_row = last_row;
     launch_fused_op9c(s, a, multicolour, nsweep, flags, k);
+  } else if (op.nterms == 3) {
+    launch_fused_op9m3(s, a, multicolour, nsweep, flags, k);
   } else {
     launch_fused_op9(s, a, multicolour, nsweep, flags, k);
   }

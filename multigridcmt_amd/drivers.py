@@ -10,6 +10,7 @@ Every V-cycle, interpolation, Gram-Schmidt and operator application runs on the 
 MGCMTProcessor; the coarse-grid ``eigsh`` stays on the host as in the reference (16 .. 256 unknowns).
 """
 import numpy as np
+import scipy.linalg
 import scipy.sparse as sparse
 import scipy.sparse.linalg as sparsela
 
@@ -88,3 +89,65 @@ def rayleigh_quotient_multigrid(gridsize=2 ** 6, first_cycles=2, second_cycles=1
         x_matrix[:, 1], rho2 = solver.vcycle_rqmg(x_matrix[:, 1], A, M)
         x_matrix = processor.gramschmidt(x_matrix)
     return rho, rho2, x_matrix
+
+
+def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8, method="vcycle", nu=2, lowest=8,
+                              smoother="rb", seed=0, history=None):
+    """BASELINE config 5: the ground state of the 2-D square well  H = -laplacian/pi^2 + V  (V = `depth` outside the
+    central square, PotWellSolver.py:150-153 carried to 2-D) by Rayleigh-quotient minimisation on the GPU.
+
+    method="rqmg"    ``cycles`` sweeps of MGCMTSolver.vcycle_rqmg (RQMin.py:25-27 with the 2-D transfers).
+    method="vcycle"  Rayleigh-quotient minimisation with a V-cycle preconditioner: every iteration applies one V(nu,nu)
+                     cycle of H (from a zero start) to the eigen-residual r = H x - rho x and minimises the Rayleigh
+                     quotient over span{x, w} — the 2x2 problem of rqmin (MGCMTSolver.py:44-50) with the
+                     preconditioned residual as the search direction.  All vector work stays in HBM; the host sees six
+                     inner products per iteration.
+    Returns (rho, x); ``history`` (a list) receives rho after every cycle."""
+    from . import _lib
+    from .operators import identity_operator, potential_well_operator
+    from .plan import get_plan
+    g = int(gridsize)
+    if inner is None:
+        inner = (g // 4, 3 * g // 4)
+    op = potential_well_operator(g, depth, inner)
+    rng = np.random.RandomState(seed)
+    x0 = rng.random_sample(g * g)
+    if method == "rqmg":
+        solver, M = MGCMTSolver(), identity_operator(g, "2d")
+        rho = 0.0
+        for _ in range(cycles):
+            x0, rho = solver.vcycle_rqmg(x0, op, M, nu1=nu, nu2=nu, nmin=lowest)
+            if history is not None:
+                history.append(rho)
+        return rho, x0
+    if method != "vcycle":
+        raise ValueError("method must be 'rqmg' or 'vcycle'")
+    kind, omega = (_lib.GS_MC, 1.0) if smoother == "rb" else (_lib.WJACOBI, 2. / 3.)
+    V, F, W = _lib.SLOT_V, _lib.SLOT_F, _lib.SLOT_W
+    X, AX, AW, PW = (W, 0), (W, 1), (W, 2), (V, 0)
+    plan = get_plan(op, int(lowest), nvec=3)
+    plan.set_shifts(np.zeros(3))
+    plan.upload(0, W, 0, x0)
+    plan.scale(0, 1.0 / np.sqrt(plan.dot(0, X, X)), X)
+    plan.apply(0, X, AX)
+    rho = plan.dot(0, X, AX)
+    for _ in range(cycles):
+        plan.copy(0, AX[0], AX[1], F, 0)                 # r = H x - rho x
+        plan.axpy(0, -rho, X, (F, 0))
+        plan.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu, zero_start=True)        # w = B r
+        plan.apply(0, PW, AW)
+        xx, xw, ww = plan.dot(0, X, X), plan.dot(0, X, PW), plan.dot(0, PW, PW)
+        xax, xaw, waw = plan.dot(0, X, AX), plan.dot(0, X, AW), plan.dot(0, PW, AW)
+        evals, evecs = scipy.linalg.eigh(np.array([[xax, xaw], [xaw, waw]]), np.array([[xx, xw], [xw, ww]]))
+        a, b = evecs[:, 0]
+        plan.scale(0, a, X)
+        plan.axpy(0, b, PW, X)
+        plan.scale(0, a, AX)
+        plan.axpy(0, b, AW, AX)
+        nrm = np.sqrt(plan.dot(0, X, X))
+        plan.scale(0, 1.0 / nrm, X)
+        plan.scale(0, 1.0 / nrm, AX)
+        rho = plan.dot(0, X, AX)
+        if history is not None:
+            history.append(rho)
+    return rho, plan.download(0, W, 0)

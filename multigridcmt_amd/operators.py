@@ -140,6 +140,33 @@ def laplacian_operator(n, dimension="1d"):
     return StructuredOperator("2d", n, [(tri_identity(n), tri_laplacian(n)), (tri_laplacian(n), tri_identity(n))])
 
 
+def identity_operator(n, dimension="1d"):
+    """sparse.eye(N) as a structured operator (the mass matrix M of rqmin, RQMin.py:18)."""
+    n = int(n)
+    if dimension == "1d":
+        return StructuredOperator("1d", n, [(None, tri_identity(n))])
+    return StructuredOperator("2d", n, [(tri_identity(n), tri_identity(n))])
+
+
+def potential_well_operator(g, depth, inner, scale=-1.0 / np.pi ** 2):
+    """H = scale * laplacian(g, "2d") + diag(V) with the square-well potential of PotWellSolver.py:150-153 carried to
+    2-D: V = `depth` outside the square [inner[0], inner[1])^2 of grid indices and 0 inside (BASELINE config 5).
+
+    V = depth * (1 - chi (x) chi) is a sum of Kronecker products of diagonal factors, so H has three terms:
+    I (x) (scale L + depth I)  +  (scale L) (x) I  -  (depth chi) (x) chi.
+    """
+    g = int(g)
+    lo, hi = int(inner[0]), int(inner[1])
+    chi = np.zeros(g)
+    chi[lo:hi] = 1.0
+    L = tri_laplacian(g) * float(scale)
+    y1 = L.copy()
+    y1[1] += float(depth)
+    dchi = np.zeros((3, g))
+    dchi[1] = chi
+    return StructuredOperator("2d", g, [(tri_identity(g), y1), (L.copy(), tri_identity(g)), (dchi * (-float(depth)), dchi.copy())])
+
+
 class UnrecognisedOperator(ValueError):
     pass
 

@@ -334,10 +334,12 @@ class MGCMTSolver:
 
     def vcycle_rqmg(self, x, A, M, nu1=4, nu2=4, nmin=2):
         """MGCMTSolver.py:99-122 — Rayleigh-quotient multigrid: rqmin, restrict the ITERATE, recurse
-        on the Galerkin pair (R A P, R M P), add the interpolated coarse iterate, rqmin; returns (k, rho)."""
+        on the Galerkin pair (R A P, R M P), add the interpolated coarse iterate, rqmin; returns (k, rho).
+        The reference only has the 1-D transfer operators here (:107-108); for a 2-D operator (a
+        StructuredOperator) the same algorithm runs with the 2-D ones and nmin counts points per direction."""
         x0 = np.asarray(x, dtype=np.float64).reshape(-1)
-        n = len(x0)
-        plan = self._rq_plan(A, M, max(int(nmin), 2) if n > nmin else n)
+        g = recognise(A).g                     # points per direction (the vector length in 1-D, as in the reference)
+        plan = self._rq_plan(A, M, max(int(nmin), 2) if g > nmin else g)
         plan.set_shifts(np.zeros(self._RQ_REGS))
         plan.upload(0, SLOT_V, self._X, x0)
         _, rho = self._rqmg_levels(plan, 0, int(nu1), int(nu2))
@@ -351,7 +353,7 @@ class MGCMTSolver:
         if nv > _lib.MAX_VEC:
             raise ValueError("at most %d columns per call" % _lib.MAX_VEC)
         opA = recognise(A)
-        plan = get_plan(opA, max(int(nmin), 2) if n > nmin else n, nvec=max(self._RQ_REGS, nv), mass=recognise(M, opA.dimension))
+        plan = get_plan(opA, max(int(nmin), 2) if opA.g > nmin else opA.g, nvec=max(self._RQ_REGS, nv), mass=recognise(M, opA.dimension))
         plan.set_shifts(np.zeros(plan.nvec))
         for i in range(nv):
             plan.upload(0, SLOT_W, i, k0[:, i])

@@ -319,15 +319,17 @@ class RefSolver:
             g = 2 * (A @ x - rho * (M @ x))
         return x, rho
 
-    def vcycle_rqmg(self, x, A, M, nu1=4, nu2=4, nmin=2):
-        """MGCMTSolver.py:99-122 — restricts the iterate itself, Galerkin A_c and M_c (:110-111)."""
+    def vcycle_rqmg(self, x, A, M, nu1=4, nu2=4, nmin=2, dimension="1d"):
+        """MGCMTSolver.py:99-122 — restricts the iterate itself, Galerkin A_c and M_c (:110-111).
+        dimension="2d" (not in the reference, whose transfers here are 1-D only, :107-108) runs the same algorithm
+        with the 2-D transfer operators; n then counts points per direction.  PARITY UNPINNED for "2d"."""
         k = np.array(x).reshape(-1)
-        n = len(k)
+        n = len(k) if dimension == "1d" else int(round(math.sqrt(len(k))))
         k, rho = self.rqmin(A, k, M, nu=nu1)
         if n > nmin:
-            P = self.stencil_maker.interpolation(n // 2, n)
-            R = self.stencil_maker.restriction(n, n // 2)
-            c, rho = self.vcycle_rqmg(R @ k, R @ A @ P, R @ M @ P, nu1=nu1, nu2=nu2, nmin=nmin)
+            P = self.stencil_maker.interpolation(n // 2, n, dimension=dimension)
+            R = self.stencil_maker.restriction(n, n // 2, dimension=dimension)
+            c, rho = self.vcycle_rqmg(R @ k, R @ A @ P, R @ M @ P, nu1=nu1, nu2=nu2, nmin=nmin, dimension=dimension)
             k = k + P @ c
             k, rho = self.rqmin(A, k, M, nu=nu2)
         return k, rho

@@ -159,3 +159,34 @@ def test_recompute_instead_of_store_is_exact(backend, kind, omega):
             outs.append(p.download(0, _lib.SLOT_V, 0))
             p.close()
         assert np.array_equal(outs[0], outs[1]), (nu1, nu2, nuc)
+
+
+def test_potential_well_operator_three_terms(backend):
+    """BASELINE config 5's operator: -laplacian/pi^2 + square-well potential = three Kronecker terms (Op9<3> on every
+    level).  Fused vs one-launch-per-operation kernels, and the sparse oracle on the assembled matrix."""
+    from multigridcmt_amd.operators import potential_well_operator
+    from oracle.sparse_ref import RefSolver, RefStencilMaker
+    g = 128
+    op = potential_well_operator(g, depth=40.0, inner=(g // 4, 3 * g // 4))
+    A = op.tocsr()
+    ii, jj = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
+    inside = (ii >= g // 4) & (ii < 3 * g // 4) & (jj >= g // 4) & (jj < 3 * g // 4)
+    assert np.allclose(A.diagonal().reshape(g, g) - (4 * g * g / np.pi ** 2), np.where(inside, 0.0, 40.0))
+    rng = np.random.RandomState(17)
+    v0, f = rng.rand(g * g), rng.rand(g * g)
+    S, SM = RefSolver(), RefStencilMaker()
+    for kind, omega, smo in ((_lib.WJACOBI, 2. / 3., S.wjacobi),
+                             (_lib.GS_MC, 1.0, lambda v, f, A, nu=4: S.gseidel_mc(v, f, A, nu=nu, dimension="2d"))):
+        outs = []
+        for fused in (1, 0):
+            p = Plan(op, 8, nvec=1)
+            p.set_option(_lib.OPT_FUSED, fused)
+            p.set_shifts([2.5])
+            p.upload(0, _lib.SLOT_V, 0, v0)
+            p.upload(0, _lib.SLOT_F, 0, f)
+            p.vcycle(2, 2, kind, omega=omega, nu_coarse=4)
+            outs.append(p.download(0, _lib.SLOT_V, 0))
+            p.close()
+        assert rel_err(outs[0], outs[1]) < 1e-11
+        y = S.vcycle(v0, f, A, SM, nu1=2, nu2=2, smoother=smo, shift=2.5, lowest_level=8, dimension="2d")
+        assert rel_err(outs[0], y) < 1e-10

@@ -293,3 +293,27 @@ def test_interpolate_restrict_match_stencil_maker_matrices(trio):
         assert rel_err(solver.interpolate(c, sm, new, dimension=dim), sm.interpolation(old, new, dimension=dim) * c) < 1e-14
         fv = rng.rand(new if dim == "1d" else new * new)
         assert rel_err(solver.restrict(fv, sm, old, dimension=dim), sm.restriction(new, old, dimension=dim) * fv) < 1e-14
+
+
+def test_rayleigh_quotient_multigrid_two_dimensional(trio):
+    """BASELINE config 5 at a size the oracle can run: Rayleigh-quotient multigrid for the ground state of a 2-D
+    square well, M = I.  The reference's vcycle_rqmg only has 1-D transfers (MGCMTSolver.py:107-108); the oracle's
+    dimension="2d" variant is the same algorithm with the 2-D ones (parity unpinned by the reference itself)."""
+    from multigridcmt_amd.operators import identity_operator, potential_well_operator
+    from oracle.sparse_ref import RefSolver
+    solver, sm, _ = trio
+    g = 32
+    op = potential_well_operator(g, depth=30.0, inner=(8, 24))
+    A, M = op.tocsr(), sp.eye(g * g, format="csr")
+    x0 = np.random.RandomState(0).rand(g * g)
+    S = RefSolver()
+    x, xr = x0.copy(), x0.copy()
+    for _ in range(2):
+        x, rho = solver.vcycle_rqmg(x, op, identity_operator(g, "2d"), nu1=3, nu2=3, nmin=4)
+        xr, rho_ref = S.vcycle_rqmg(xr, A, M, nu1=3, nu2=3, nmin=4, dimension="2d")
+        assert abs(rho - np.real(rho_ref)) < NORTH_STAR * abs(np.real(rho_ref))
+    assert rel_err(x, np.real(xr)) < 1e-8
+    # and it is an eigenvalue estimate from above that two cycles bring close to the lowest eigenvalue
+    import scipy.sparse.linalg as sla
+    lowest = sla.eigsh(A, k=1, which="SA")[0][0]
+    assert lowest <= rho < lowest * 1.05
