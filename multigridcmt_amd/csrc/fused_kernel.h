@@ -32,12 +32,12 @@ namespace fused {
 #define MGCMT_FUSED_ROWS 0
 #endif
 #ifndef MGCMT_FUSED_DEPTH
-#define MGCMT_FUSED_DEPTH 4
+#define MGCMT_FUSED_DEPTH 3
 #endif
 #ifndef MGCMT_FUSED_WAVES
 #define MGCMT_FUSED_WAVES 1
 #endif
-constexpr int kDepth = MGCMT_FUSED_DEPTH;         // rows per prefetch batch (two batches of registers)
+constexpr int kDepth = MGCMT_FUSED_DEPTH;         // rows per prefetch batch (two batches of registers); 1, 3 or 6
 constexpr int kWavesPerBlock = MGCMT_FUSED_WAVES;
 #ifndef MGCMT_FUSED_DEPTH9
 #define MGCMT_FUSED_DEPTH9 1
@@ -103,6 +103,15 @@ __device__ __forceinline__ void store2_stream(double* p, double x, double y) {
 
 constexpr int round_even(int x) { return (x + 1) & ~1; }
 
+// value of `v` in the lane whose byte address (4 * lane) is given: the shuffles of the marching loop read the
+// neighbouring lanes through two precomputed addresses instead of recomputing them at every call
+__device__ __forceinline__ double lane_fetch(int byte_addr, double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // Arithmetic note: multiply-adds are written as explicit fma() (fewer VALU issues; measured -10 % on a 4096^2
 // cycle) rather than left to -ffp-contract, so that every instantiation rounds identically: the "recompute instead
 // of store" passes must reproduce the stored values bit for bit.
@@ -123,60 +132,71 @@ struct Op5 {
     cw = a.cw;
   }
   static constexpr int kRowValues = 0;  // per-row operator data staged through LDS (none)
+  static constexpr bool kSpecialRow = false;
   __device__ __forceinline__ double fetch_row(const FusedArgs&, long, int) const { return 0.0; }
-  __device__ __forceinline__ void set_row(const FusedArgs&, long, const double*) {}
+  __device__ __forceinline__ void set_row(const FusedArgs&, int, const double*) {}
+  __device__ __forceinline__ bool special_row(int) const { return false; }
   template <int COL>
   __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
     off = fma(cn, n[1] + s[1], cw * (c[0] + c[2]));
     dg = d;
     inv = invd;
   }
+  template <int COL>
+  __device__ __forceinline__ void fix_special(const double*, double&, double&, double&) const {}
 };
 
 // Galerkin coarsenings of a constant operator: every factor is Toeplitz except its last diagonal entry
 // (MGCMTSolver.py:318 with the one-sided P/R of MGCMTStencilMaker.py:27-78), so the 9 coefficients are
-// constants with corrections on the last row, the last column and the corner.  No coefficient loads.
+// constants with corrections on the last row, the last column and the corner.  No coefficient loads: the interior
+// coefficients are wave-uniform (scalar registers); the last COLUMN only changes the centre-column coefficients of
+// the lane that owns it, which are per-lane values set up once; the last ROW is one marching step per stage and is
+// patched by a wave-uniform branch (fix_special).
 struct Op9c {
   static constexpr bool kNine = true;
-  double cnw, cn_, cne, cw_, cc_, ce_, csw, cs_, cse;  // interior
-  double rw, rc, re;                                     // own-row coefficients on the last row
-  double kn, kc, ks, kcr;                                // centre-column coefficients on the last column (kcr: corner)
-  double mu;
-  double lastb;  // 1.0 when column ja+1 is the last column, else 0.0 (arithmetic blends, no data-dependent selects of members)
-  long last_row_index;
-  double lr;     // 1.0 on the last row
-  double i00, ir, ic, irc;
+  static constexpr bool kSpecialRow = true;
+  double cnw, cn_, cne, cw_, ce_, csw, cs_, cse;  // interior (uniform)
+  double vnb, vsb;                                  // north / south coefficients of column ja+1 (per lane)
+  double dga, dgb, inva, invb;                      // diagonal of (A - mu I) and its reciprocal: column ja (uniform), ja+1 (per lane)
+  double rw, re;                                    // last row: additions to the west / east coefficients
+  double dgra, dgrb, invra, invrb;                  // last row: diagonals
+  int last_row_index;
   __device__ __forceinline__ void init(const FusedArgs& a, int q, long ja, long nc) {
     cnw = a.c9[0][0]; cn_ = a.c9[0][1]; cne = a.c9[0][2];
-    cw_ = a.c9[1][0]; cc_ = a.c9[1][1]; ce_ = a.c9[1][2];
+    cw_ = a.c9[1][0]; ce_ = a.c9[1][2];
     csw = a.c9[2][0]; cs_ = a.c9[2][1]; cse = a.c9[2][2];
-    // stored as differences to the interior values so that a row / column flag blends them in
-    rw = a.c9row[0] - cw_; rc = a.c9row[1] - cc_; re = a.c9row[2] - ce_;
-    kn = a.c9col[0] - cn_; kc = a.c9col[1] - cc_; ks = a.c9col[2] - cs_;
-    kcr = a.c9corner - a.c9row[1] - a.c9col[1] + cc_;
-    mu = a.shifts[q];
-    lastb = (ja + 1 == nc - 1) ? 1.0 : 0.0;
-    last_row_index = a.last_row;
-    lr = 0.0;
-    // reciprocals of the four possible diagonals (interior, last row, last column, corner), as blends
-    i00 = 1.0 / (cc_ - mu);
-    const double i10 = 1.0 / (a.c9row[1] - mu), i01 = 1.0 / (a.c9col[1] - mu), i11 = 1.0 / (a.c9corner - mu);
-    ir = i10 - i00;
-    ic = i01 - i00;
-    irc = i11 - i10 - i01 + i00;
+    const double mu = a.shifts[q];
+    const bool lastb = ja + 1 == nc - 1;
+    vnb = lastb ? a.c9col[0] : cn_;
+    vsb = lastb ? a.c9col[2] : cs_;
+    dga = a.c9[1][1] - mu;
+    dgb = (lastb ? a.c9col[1] : a.c9[1][1]) - mu;
+    inva = 1.0 / dga;
+    invb = 1.0 / dgb;
+    rw = a.c9row[0] - cw_;
+    re = a.c9row[2] - ce_;
+    dgra = a.c9row[1] - mu;
+    dgrb = (lastb ? a.c9corner : a.c9row[1]) - mu;
+    invra = 1.0 / dgra;
+    invrb = 1.0 / dgrb;
+    last_row_index = (int)a.last_row;
   }
   static constexpr int kRowValues = 0;
   __device__ __forceinline__ double fetch_row(const FusedArgs&, long, int) const { return 0.0; }
-  __device__ __forceinline__ void set_row(const FusedArgs&, long row, const double*) { lr = row == last_row_index ? 1.0 : 0.0; }
+  __device__ __forceinline__ void set_row(const FusedArgs&, int, const double*) {}
+  __device__ __forceinline__ bool special_row(int row) const { return row == last_row_index; }
   template <int COL>
   __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
-    const double lc = COL == 1 ? lastb : 0.0;
-    const double w = fma(lr, rw, cw_), e = fma(lr, re, ce_);
-    const double vn = fma(lc, kn, cn_), vs = fma(lc, ks, cs_);
-    const double vc = fma(lr * lc, kcr, fma(lc, kc, fma(lr, rc, cc_)));
-    off = fma(cse, s[2], fma(vs, s[1], fma(csw, s[0], fma(e, c[2], fma(w, c[0], fma(cne, n[2], fma(vn, n[1], cnw * n[0])))))));
-    dg = vc - mu;
-    inv = fma(lr * lc, irc, fma(lc, ic, fma(lr, ir, i00)));
+    const double vn = COL == 1 ? vnb : cn_, vs = COL == 1 ? vsb : cs_;
+    off = fma(cse, s[2], fma(vs, s[1], fma(csw, s[0], fma(ce_, c[2], fma(cw_, c[0], fma(cne, n[2], fma(vn, n[1], cnw * n[0])))))));
+    dg = COL == 1 ? dgb : dga;
+    inv = COL == 1 ? invb : inva;
+  }
+  template <int COL>
+  __device__ __forceinline__ void fix_special(const double* c, double& off, double& dg, double& inv) const {
+    off = fma(re, c[2], fma(rw, c[0], off));
+    dg = COL == 1 ? dgrb : dgra;
+    inv = COL == 1 ? invrb : invra;
   }
 };
 
@@ -188,6 +208,7 @@ struct Op9c {
 template <int M>
 struct Op9 {
   static constexpr bool kNine = true;
+  static constexpr bool kSpecialRow = false;
   static constexpr int kRowValues = 3 * M;
   double mu;
   double ya[M][3], yb[M][3];  // lower, diag, upper of Y_m at columns ja, ja+1
@@ -208,12 +229,15 @@ struct Op9 {
     const int k = lane < 3 * M ? lane : 3 * M - 1;
     return a.X[k / 3][(k % 3) * a.ldx + rl];
   }
-  __device__ __forceinline__ void set_row(const FusedArgs&, long, const double* ring_row) {
+  __device__ __forceinline__ void set_row(const FusedArgs&, int, const double* ring_row) {
 #pragma unroll
     for (int m = 0; m < M; ++m)
 #pragma unroll
       for (int p = 0; p < 3; ++p) x[m][p] = ring_row[3 * m + p];
   }
+  __device__ __forceinline__ bool special_row(int) const { return false; }
+  template <int COL>
+  __device__ __forceinline__ void fix_special(const double*, double&, double&, double&) const {}
   template <int COL>
   __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
     double o = 0.0, dd = 0.0;
@@ -266,6 +290,26 @@ struct FusedShape {
 // kNoStore + NPRE: "recompute instead of store" — the down-leg pass writes only the restricted residual, the
 // up-leg pass re-runs the same pre-smoothing sweeps from the untouched V before it adds the correction
 // (identical arithmetic, hence identical values): 8 B per point less written and 8 B less read per level.
+//
+// Instruction economy (these kernels keep the vector ALUs 40-60 % busy, so instructions are time):
+//  * the marching loop body is six steps long and every step knows its position T in it at compile time, so the
+//    three-row stage windows and the right-hand-side delay line are ROTATING register files indexed by T — a row
+//    is written once and never moved;
+//  * no per-stage masks: columns outside the grid carry omega = 0 (their value stays at the zero it was loaded
+//    as), rows outside the grid skip the stage under a wave-uniform branch;
+//  * row/column indices are 32-bit (wave-uniform tests stay on the scalar unit), only row offsets are 64-bit and
+//    advance incrementally.
+constexpr int mod3(int x) { return ((x % 3) + 3) % 3; }
+constexpr int mod6(int x) { return ((x % 6) + 6) % 6; }
+template <int N>
+struct StepIndex {
+  static constexpr int value = N;
+};
+template <bool B>
+struct Checked {
+  static constexpr bool value = B;
+};
+
 template <class OP, int KIND, int NSWEEP, int FLAGS>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   using Shape = FusedShape<OP, KIND, NSWEEP, FLAGS>;
@@ -275,6 +319,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   constexpr bool NINE = OP::kNine;
   constexpr int WN = NINE ? S + E : 1;  // windows that also keep the lateral neighbours
   constexpr int D = NINE ? kDepth9 : kDepth;  // rows per prefetch batch
+  static_assert(6 % D == 0 && (6 / D) % 2 == 0, "the six-step loop body must hold an even number of prefetch batches");
+  constexpr int FL = S + E + 1;               // delay of the right-hand side between its load and its last use
+  constexpr bool FRING = FL <= 6;             // short enough for a rotating file of six; otherwise a shifting one
+  constexpr int FN = FRING ? 6 : FL;
 
   // workgroup -> (column group, row chunk).  Blocks b and b+8 run on the same XCD (own L2): an XCD gets a
   // CONTIGUOUS range of column groups, so the half cache lines two neighbouring windows share (their 8-column
@@ -294,15 +342,21 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
 #endif
   if (group >= a.n_col_groups) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long strip = (long)group * kWavesPerBlock + wave;
-  if (strip * WOUT >= a.nc) return;  // wave-uniform
+  const int lane_up = (lane > 0 ? lane - 1 : 0) << 2, lane_dn = (lane < 63 ? lane + 1 : 63) << 2;  // left / right neighbour
+  const int strip = group * kWavesPerBlock + wave;
+  const int nc = (int)a.nc, nr = (int)a.nr, cnc = (int)a.cnc;
+  const int row_lo = (int)a.row_lo, row_hi = (int)a.row_hi;
+  if (strip * WOUT >= nc) return;  // wave-uniform
   const int q = blockIdx.y;
 
-  const long ja = strip * WOUT - HALO + 2 * lane;  // this lane's columns: ja (even), ja + 1
-  const bool col_in = ja >= 0 && ja < a.nc;
+  const int ja = strip * WOUT - HALO + 2 * lane;  // this lane's columns: ja (even), ja + 1
+  const bool col_in = ja >= 0 && ja < nc;
   const bool col_out = col_in && 2 * lane >= HALO && 2 * lane < HALO + WOUT;
-  const long jc = ja >> 1;  // coarse column of the pair
-  const bool ccol_in = jc >= 0 && jc < a.cnc;
+  const int jc = ja >> 1;  // coarse column of the pair
+  const bool ccol_in = jc >= 0 && jc < cnc;
+  const double lanemask = col_in ? 1.0 : 0.0;    // multiplies what is loaded for columns outside the grid
+  const double cmask = ccol_in ? 1.0 : 0.0;
+  const double omega = col_in ? a.omega : 0.0;   // ... and they are never updated: Dirichlet ghosts stay zero
 
   const double* __restrict__ vin = a.vin + q * a.vstride;
   const double* __restrict__ fin = a.f + q * a.vstride;
@@ -310,27 +364,24 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   const double* __restrict__ ec = PROLONG ? a.ec + q * a.cstride : nullptr;
   double* __restrict__ rc = RESTRICT ? a.rc + q * a.cstride : nullptr;
 
-  const double omega = a.omega;
-  const long nc = a.nc;
+  const int r_begin = chunk * a.rows_per_chunk;
+  const int r_end = r_begin + a.rows_per_chunk < nr ? r_begin + a.rows_per_chunk : nr;
+  const int rstart = r_begin - (S + E);
+  const int rstop = r_end + S + 2 * E;  // rows [rstart, rstop) are read
 
-  const long r_begin = (long)chunk * a.rows_per_chunk;
-  const long r_end = r_begin + a.rows_per_chunk < a.nr ? r_begin + a.rows_per_chunk : a.nr;
-  const long rstart = r_begin - (S + E);
-  const long rstop = r_end + S + 2 * E;  // rows [rstart, rstop) are read
-
-  auto row_ok = [&](long row) { return row >= a.row_lo && row < a.row_hi; };
+  auto row_ok = [&](int row) { return row >= row_lo && row < row_hi; };
 
   // Loads are unconditional (addresses clamped into the allocation, values masked when they are
   // consumed): with no branch around a load the compiler's vmcnt bookkeeping stays exact.
-  const long ja_ld = ja < 0 ? 0 : (ja > nc - 2 ? nc - 2 : ja);
-  const long jc_ld = jc < 0 ? 0 : (jc > a.cnc - 1 ? a.cnc - 1 : jc);
-  const long crow_lo = (a.row_lo >> 1) - 1, crow_hi = (a.row_hi - 1) >> 1;  // coarse rows that may be read
+  const int ja_ld = ja < 0 ? 0 : (ja > nc - 2 ? nc - 2 : ja);
+  const int jc_ld = jc < 0 ? 0 : (jc > cnc - 1 ? cnc - 1 : jc);
+  const int crow_lo = (row_lo >> 1) - 1, crow_hi = (row_hi - 1) >> 1;  // coarse rows that may be read
 
   OP op;
   op.init(a, q, ja, nc);
 
-  // Two register sets A/B of kDepth rows each, used alternately: one is refilled while the other is
-  // consumed, so every load has kDepth rows of work between its issue and its use.
+  // Two register sets A/B of D rows each, used alternately: one is refilled while the other is
+  // consumed, so every load has D rows of work between its issue and its use.
   struct Row {
     double2 v, f;
     double e;
@@ -341,25 +392,34 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   __shared__ double s_ring[kWavesPerBlock][RV > 0 ? kRing * RV : 1];
   double* ring = s_ring[wave];
   Row setA[D], setB[D];
-  auto fetch = [&](long row, Row& r) __attribute__((always_inline)) {
-    const long rl = row < a.row_lo ? a.row_lo : (row >= a.row_hi ? a.row_hi - 1 : row);
+  // rows are fetched in order; the row is clamped into the allocation with min/max (no control flow near a load)
+  int frow = rstart;
+  auto fetch = [&](Row& r) __attribute__((always_inline)) {
+    const int hi = row_hi - 1;
+    const int t = frow < hi ? frow : hi;
+    const int frl = t > row_lo ? t : row_lo;
+    const long fbase = (long)frl * nc;
     if (ZERO_IN) r.v = make_double2(0.0, 0.0);
-    else r.v = load2(vin + rl * nc + ja_ld);
-    r.f = load2_stream(fin + rl * nc + ja_ld);
+    else r.v = load2(vin + fbase + ja_ld);
+    r.f = load2_stream(fin + fbase + ja_ld);
     r.e = 0.0;
     if (PROLONG) {
-      const long I = rl >> 1;
-      r.e = ec[(I < crow_lo ? crow_lo : (I > crow_hi ? crow_hi : I)) * a.cnc + jc_ld];
+      const int I0 = frl >> 1;
+      const int I1 = I0 < crow_hi ? I0 : crow_hi;
+      const int I = I1 > crow_lo ? I1 : crow_lo;
+      r.e = ec[I * cnc + jc_ld];
     }
-    r.xr = RV > 0 ? op.fetch_row(a, rl, lane) : 0.0;
+    r.xr = RV > 0 ? op.fetch_row(a, frl, lane) : 0.0;
+    ++frow;
   };
 #pragma unroll
-  for (int u = 0; u < D; ++u) fetch(rstart + u, setA[u]);
+  for (int u = 0; u < D; ++u) fetch(setA[u]);
 
-  // stage windows: w[s] is the input of stage s+1; w[S] (RESTRICT) the input of the residual stage.
-  // [0] row above, [1] the row being updated, [2] row below; wl / wr: values left of ja / right of ja+1
+  // stage windows: w[s] is the input of stage s+1; w[S] (RESTRICT) the input of the residual stage.  Three rows
+  // each, rotating: at loop position T stage s finds the row above / the row it updates / the row below (just
+  // arrived) in slots mod3(T-s+1) / mod3(T-s+2) / mod3(T-s).  wl / wr: values left of ja / right of ja+1.
   double wa[S + E][3], wb[S + E][3], wl[WN][3], wr[WN][3];
-  double fa[S + E + 1], fb[S + E + 1];
+  double fa[FN], fb[FN];
 #pragma unroll
   for (int s = 0; s < S + E; ++s)
 #pragma unroll
@@ -369,173 +429,223 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) wl[s][r] = wr[s][r] = 0.0;
 #pragma unroll
-  for (int s = 0; s <= S + E; ++s) fa[s] = fb[s] = 0.0;
+  for (int s = 0; s < FN; ++s) fa[s] = fb[s] = 0.0;
 
-  // coarse correction values of the last SPRE+2 fine rows: er[k] belongs to fine row (row - k)
-  double er[SPRE + 2];
+  // coarse correction values of the last SPRE+2 fine rows: er[k] belongs to fine row (row - k); el[k] is the
+  // value of the lane to the left
+  double er[SPRE + 2], el[SPRE + 2];
 #pragma unroll
-  for (int k = 0; k < SPRE + 2; ++k) er[k] = 0.0;
+  for (int k = 0; k < SPRE + 2; ++k) er[k] = el[k] = 0.0;
   if (PROLONG) {
     // coarse row of fine row rstart-1 (used when rstart is even); row (row_lo>>1)-1 is the halo row
-    const long I = (rstart - 1) >> 1;
-    if (ccol_in && I >= crow_lo && I <= crow_hi) er[0] = ec[I * a.cnc + jc];
+    const int I = (rstart - 1) >> 1;
+    if (ccol_in && I >= crow_lo && I <= crow_hi) er[0] = ec[I * cnc + jc];
+    el[0] = lane_fetch(lane_up, er[0]);
   }
   double racc = 0.0;  // running full-weighting sum of the current coarse row (RESTRICT)
+  unsigned okbits = 0;  // bit k: row (row - k) lies inside the grid (wave-uniform shift register)
+  // Row parities are compile-time: chunks start on even rows (rows_per_chunk is even, so are the strip bounds)
+  // and the loop advances six rows per iteration, so the row of stage s at loop position T has the parity of
+  // T - (s + 1) - (S + E).
 
-  // push a finished row into window s (and, for 9-point operators, fetch its lateral neighbours)
-  auto push = [&](int s, double na, double nb) __attribute__((always_inline)) {
-    wa[s][0] = wa[s][1];
-    wa[s][1] = wa[s][2];
-    wa[s][2] = na;
-    wb[s][0] = wb[s][1];
-    wb[s][1] = wb[s][2];
-    wb[s][2] = nb;
-    if (NINE) {
-      wl[s][0] = wl[s][1];
-      wl[s][1] = wl[s][2];
-      wl[s][2] = __shfl_up(nb, 1);
-      wr[s][0] = wr[s][1];
-      wr[s][1] = wr[s][2];
-      wr[s][2] = __shfl_down(na, 1);
-    }
-  };
-  // neighbourhood of column ja (COL 0) / ja+1 (COL 1) in window s, handed to the operator policy
-  auto eval_a = [&](int s, double& off, double& dg, double& inv) __attribute__((always_inline)) {
-    if constexpr (NINE) {
-      const double n[3] = {wl[s][0], wa[s][0], wb[s][0]}, c[3] = {wl[s][1], wa[s][1], wb[s][1]}, so[3] = {wl[s][2], wa[s][2], wb[s][2]};
-      op.template eval<0>(n, c, so, off, dg, inv);
-    } else {
-      const double left = __shfl_up(wb[s][1], 1);
-      const double n[3] = {0.0, wa[s][0], 0.0}, c[3] = {left, wa[s][1], wb[s][1]}, so[3] = {0.0, wa[s][2], 0.0};
-      op.template eval<0>(n, c, so, off, dg, inv);
-    }
-  };
-  auto eval_b = [&](int s, double& off, double& dg, double& inv) __attribute__((always_inline)) {
-    if constexpr (NINE) {
-      const double n[3] = {wa[s][0], wb[s][0], wr[s][0]}, c[3] = {wa[s][1], wb[s][1], wr[s][1]}, so[3] = {wa[s][2], wb[s][2], wr[s][2]};
-      op.template eval<1>(n, c, so, off, dg, inv);
-    } else {
-      const double right = __shfl_down(wa[s][1], 1);
-      const double n[3] = {0.0, wb[s][0], 0.0}, c[3] = {wa[s][1], wb[s][1], right}, so[3] = {0.0, wb[s][2], 0.0};
-      op.template eval<1>(n, c, so, off, dg, inv);
-    }
-  };
-
-  // one marching step: consume the prefetched row `row`, run every stage one row further
-  auto step = [&](const long row, const Row& in) __attribute__((always_inline)) {
+  // one marching step at loop position T: consume the prefetched row `row`, run every stage one row further
+  // CHK = false: every row any stage touches in this step lies inside the grid and inside the chunk's output
+  // range (the steady state of a long march) — no row tests at all
+  auto step = [&](auto pos, auto chk, const int row, const Row& in) __attribute__((always_inline)) {
+    constexpr int T = decltype(pos)::value;
+    constexpr bool CHK = decltype(chk)::value;
     if (RV > 0 && lane < RV) ring[(row & (kRing - 1)) * RV + lane] = in.xr;  // this row's operator values
-    const bool in_dom = col_in && row_ok(row);
-    double ina = in_dom ? in.v.x : 0.0, inb = in_dom ? in.v.y : 0.0;
-    const double fna = in_dom ? in.f.x : 0.0, fnb = in_dom ? in.f.y : 0.0;
+    const bool rok = CHK ? row_ok(row) : true;
+    if (CHK) okbits = (okbits << 1) | (rok ? 1u : 0u);
+    double ina = 0.0, inb = 0.0;
+    if (!ZERO_IN) {
+      const double m = rok ? lanemask : 0.0;
+      ina = in.v.x * m;
+      inb = in.v.y * m;
+    }
 
     if (PROLONG) {
 #pragma unroll
-      for (int k = SPRE + 1; k > 0; --k) er[k] = er[k - 1];
-      er[0] = (ccol_in && row_ok(row)) ? in.e : 0.0;
+      for (int k = SPRE + 1; k > 0; --k) {
+        er[k] = er[k - 1];
+        el[k] = el[k - 1];
+      }
+      er[0] = in.e * (rok ? cmask : 0.0);
+      el[0] = lane_fetch(lane_up, er[0]);
     }
     // V += P e on fine row r (values va, vb of this lane's columns): odd fine column takes c[J], even takes
     // (c[J-1] + c[J]) / 2; an even fine row takes the mean of coarse rows I-1 and I
-    auto correct = [&](long r, double& va, double& vb) __attribute__((always_inline)) {
+    // (lag = row - r; the correction of a row outside the grid is built from zeros, so it needs no row test)
+    auto correct = [&](int lag, double& va, double& vb) __attribute__((always_inline)) {
       const double e_cur = er[SPRE], e_prev = er[SPRE + 1];
-      const double el = __shfl_up(e_cur, 1), pl = __shfl_up(e_prev, 1);
-      double ca = 0.5 * (el + e_cur), cb = e_cur;
-      if ((r & 1) == 0) {
-        ca = 0.5 * (0.5 * (pl + e_prev) + ca);
+      double ca = 0.5 * (el[SPRE] + e_cur), cb = e_cur;
+      if (((T - lag - (S + E)) & 1) == 0) {
+        ca = 0.5 * (0.5 * (el[SPRE + 1] + e_prev) + ca);
         cb = 0.5 * (e_prev + cb);
       }
-      if (col_in && row_ok(r)) {
-        va += ca;
-        vb += cb;
-      }
+      const double m = (!CHK || ((okbits >> lag) & 1u)) ? lanemask : 0.0;
+      va = fma(m, ca, va);
+      vb = fma(m, cb, vb);
     };
-    if (PROLONG && SPRE == 0) correct(row, ina, inb);
+    if (PROLONG && SPRE == 0) correct(0, ina, inb);
 
+    // right-hand side of row (row - k): slot mod6(T - k) of the rotating file, or entry k of the shifting one
+    if (FRING) {
+      fa[T] = in.f.x;
+      fb[T] = in.f.y;
+    } else {
 #pragma unroll
-    for (int s = S + E; s > 0; --s) {
-      fa[s] = fa[s - 1];
-      fb[s] = fb[s - 1];
+      for (int s = FN - 1; s > 0; --s) {
+        fa[s] = fa[s - 1];
+        fb[s] = fb[s - 1];
+      }
+      fa[0] = in.f.x;
+      fb[0] = in.f.y;
     }
-    fa[0] = fna;
-    fb[0] = fnb;
 
     double oa = ina, ob = inb;  // output of the previous stage = next input row
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      push(s, oa, ob);
-      const long rs = row - (s + 1);  // the row this stage completes now
-      const double ca = wa[s][1], cb = wb[s][1];
-      const bool live = col_in && row_ok(rs);  // outside the grid the value stays zero
-      bool upd_a = true, upd_b = true;
-      if (KIND == kRedBlack) {
-        const bool red = (s & 1) == 0;
-        const bool row_odd = (rs & 1) != 0;
-        upd_a = red == row_odd;  // column ja is even: it is red ((i+j) odd) iff the row is odd
-        upd_b = !upd_a;
-      } else if (KIND == kFourColour) {
-        // colours (i%2, j%2) in the order (0,1),(1,0),(0,0),(1,1)
-        const int c = s & 3;
-        const int cra = (c == 1 || c == 3) ? 1 : 0, ccb = (c == 0 || c == 3) ? 1 : 0;
-        const bool row_on = (int)(rs & 1) == cra;
-        upd_a = row_on && ccb == 0;
-        upd_b = row_on && ccb == 1;
+    for (int s = 0; s <= S; ++s) {
+      if (s == S && !RESTRICT) break;
+      // the window of stage s (s == S: the residual stage) takes the row the previous stage has just finished
+      const int sn = mod3(T - s), sa = mod3(T - s + 1), sc = mod3(T - s + 2);
+      wa[s][sn] = oa;
+      wb[s][sn] = ob;
+      const int sw = NINE ? s : 0;
+      if (NINE) {
+        wl[sw][sn] = lane_fetch(lane_up, ob);
+        wr[sw][sn] = lane_fetch(lane_dn, oa);
       }
-      double na = ca, nb = cb;
-      if (upd_a || upd_b) {  // wave-uniform
-        op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
-        if (upd_a) {
-          double off, dg, inv;
-          eval_a(s, off, dg, inv);
-          na = fma(omega, (fa[s + 1] - fma(dg, ca, off)) * inv, ca);
+      const int rs = row - (s + 1);  // the row this stage completes now
+      const double ca = wa[s][sc], cb = wb[s][sc];
+      const double fva = FRING ? fa[mod6(T - (s + 1))] : fa[s + 1], fvb = FRING ? fb[mod6(T - (s + 1))] : fb[s + 1];
+      // neighbourhood of column ja / ja+1, handed to the operator policy
+      auto eval_a = [&](double& off, double& dg, double& inv) __attribute__((always_inline)) {
+        if constexpr (NINE) {
+          const double n[3] = {wl[sw][sa], wa[s][sa], wb[s][sa]}, c[3] = {wl[sw][sc], ca, cb}, so[3] = {wl[sw][sn], wa[s][sn], wb[s][sn]};
+          op.template eval<0>(n, c, so, off, dg, inv);
+          if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<0>(c, off, dg, inv);
+        } else {
+          const double left = lane_fetch(lane_up, cb);
+          const double n[3] = {0.0, wa[s][sa], 0.0}, c[3] = {left, ca, cb}, so[3] = {0.0, wa[s][sn], 0.0};
+          op.template eval<0>(n, c, so, off, dg, inv);
         }
-        if (upd_b) {
-          double off, dg, inv;
-          eval_b(s, off, dg, inv);
-          nb = fma(omega, (fb[s + 1] - fma(dg, cb, off)) * inv, cb);
+      };
+      auto eval_b = [&](double& off, double& dg, double& inv) __attribute__((always_inline)) {
+        if constexpr (NINE) {
+          const double n[3] = {wa[s][sa], wb[s][sa], wr[sw][sa]}, c[3] = {ca, cb, wr[sw][sc]}, so[3] = {wa[s][sn], wb[s][sn], wr[sw][sn]};
+          op.template eval<1>(n, c, so, off, dg, inv);
+          if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<1>(c, off, dg, inv);
+        } else {
+          const double right = lane_fetch(lane_dn, ca);
+          const double n[3] = {0.0, wb[s][sa], 0.0}, c[3] = {ca, cb, right}, so[3] = {0.0, wb[s][sn], 0.0};
+          op.template eval<1>(n, c, so, off, dg, inv);
         }
-      }
-      oa = live ? na : 0.0;
-      ob = live ? nb : 0.0;
-      if (PROLONG && SPRE > 0 && s == SPRE - 1) correct(rs, oa, ob);  // the recomputed pre-smoothing ends here
-    }
+      };
 
-    const long rout = row - S;
-    if (STORE_V && col_out && rout >= r_begin && rout < r_end) store2_stream(vout + rout * nc + ja, oa, ob);
-
-    if (RESTRICT) {
-      push(S, oa, ob);
-      const long rr = row - (S + 1);  // residual row completed now
-      const double ca = wa[S][1], cb = wb[S][1];
-      op.set_row(a, rr, ring + (rr & (kRing - 1)) * RV);
-      double offa, offb, dga, dgb, inva, invb;
-      eval_a(S, offa, dga, inva);
-      eval_b(S, offb, dgb, invb);
-      double ra = 0.0, rb = 0.0;
-      if (col_in && row_ok(rr)) {
-        ra = fa[S + 1] - fma(dga, ca, offa);
-        rb = fb[S + 1] - fma(dgb, cb, offb);
-      }
-      const double rnext = __shfl_down(ra, 1);  // residual at column ja + 2
-      const double h = 0.25 * ra + 0.5 * rb + 0.25 * rnext;
-      if ((rr & 1) == 0) {
-        const long I = (rr >> 1) - 1;  // coarse row closed by fine row rr = 2I + 2
-        if (col_out && ccol_in && 2 * I >= r_begin && 2 * I < r_end) rc[I * a.cnc + jc] = racc + 0.25 * h;
-        racc = 0.25 * h;
+      if (s < S) {
+        const int rs_par = (T - (s + 1) - (S + E)) & 1;  // parity of rs
+        bool upd_a = true, upd_b = true;
+        if (KIND == kRedBlack) {
+          const bool red = (s & 1) == 0;
+          const bool row_odd = rs_par != 0;
+          upd_a = red == row_odd;  // column ja is even: it is red ((i+j) odd) iff the row is odd
+          upd_b = !upd_a;
+        } else if (KIND == kFourColour) {
+          // colours (i%2, j%2) in the order (0,1),(1,0),(0,0),(1,1)
+          const int c = s & 3;
+          const int cra = (c == 1 || c == 3) ? 1 : 0, ccb = (c == 0 || c == 3) ? 1 : 0;
+          const bool row_on = rs_par == cra;
+          upd_a = row_on && ccb == 0;
+          upd_b = row_on && ccb == 1;
+        }
+        double na = ca, nb = cb;
+        // wave-uniform; outside the grid (a few steps of the first and last chunks) the value stays zero
+        if ((upd_a || upd_b) && (!CHK || ((okbits >> (s + 1)) & 1u) != 0)) {
+          op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
+          if (upd_a) {
+            double off, dg, inv;
+            eval_a(off, dg, inv);
+            na = fma(omega, (fva - fma(dg, ca, off)) * inv, ca);
+          }
+          if (upd_b) {
+            double off, dg, inv;
+            eval_b(off, dg, inv);
+            nb = fma(omega, (fvb - fma(dg, cb, off)) * inv, cb);
+          }
+        }
+        oa = na;
+        ob = nb;
+        if (PROLONG && SPRE > 0 && s == SPRE - 1) correct(s + 1, oa, ob);  // the recomputed pre-smoothing ends here
+        if (s == S - 1) {
+          const int rout = row - S;
+          if (STORE_V && col_out && (!CHK || (rout >= r_begin && rout < r_end))) store2_stream(vout + (long)rout * nc + ja, oa, ob);
+        }
       } else {
-        racc += 0.5 * h;
+        // residual of row rs and its full-weighting restriction
+        double ra = 0.0, rb = 0.0;
+        if (!CHK || ((okbits >> (s + 1)) & 1u) != 0) {
+          op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
+          double offa, offb, dga, dgb, inva, invb;
+          eval_a(offa, dga, inva);
+          eval_b(offb, dgb, invb);
+          ra = lanemask * (fva - fma(dga, ca, offa));
+          rb = lanemask * (fvb - fma(dgb, cb, offb));
+        }
+        const double rnext = lane_fetch(lane_dn, ra);  // residual at column ja + 2
+        const double h = 0.25 * ra + 0.5 * rb + 0.25 * rnext;
+        if (((T - (s + 1) - (S + E)) & 1) == 0) {
+          const int I = (rs >> 1) - 1;  // coarse row closed by fine row rs = 2I + 2
+          if (col_out && ccol_in && (!CHK || (2 * I >= r_begin && 2 * I < r_end))) rc[I * cnc + jc] = racc + 0.25 * h;
+          racc = 0.25 * h;
+        } else {
+          racc += 0.5 * h;
+        }
       }
     }
   };
 
-  // Batches: fetch a whole set, then process the other one.
-  for (long base = rstart; base < rstop; base += 2 * D) {
+  // Six steps per iteration in 6/D batches: fetch a whole set, then process the other one.
+  auto body = [&](auto chk, const int base) __attribute__((always_inline)) {
+    if constexpr (D == 3) {
 #pragma unroll
-    for (int u = 0; u < D; ++u) fetch(base + D + u, setB[u]);
+      for (int u = 0; u < 3; ++u) fetch(setB[u]);
+      step(StepIndex<0>{}, chk, base + 0, setA[0]);
+      step(StepIndex<1>{}, chk, base + 1, setA[1]);
+      step(StepIndex<2>{}, chk, base + 2, setA[2]);
 #pragma unroll
-    for (int u = 0; u < D; ++u) step(base + u, setA[u]);
-#pragma unroll
-    for (int u = 0; u < D; ++u) fetch(base + 2 * D + u, setA[u]);
-#pragma unroll
-    for (int u = 0; u < D; ++u) step(base + D + u, setB[u]);
+      for (int u = 0; u < 3; ++u) fetch(setA[u]);
+      step(StepIndex<3>{}, chk, base + 3, setB[0]);
+      step(StepIndex<4>{}, chk, base + 4, setB[1]);
+      step(StepIndex<5>{}, chk, base + 5, setB[2]);
+    } else if constexpr (D == 1) {
+      fetch(setB[0]);
+      step(StepIndex<0>{}, chk, base + 0, setA[0]);
+      fetch(setA[0]);
+      step(StepIndex<1>{}, chk, base + 1, setB[0]);
+      fetch(setB[0]);
+      step(StepIndex<2>{}, chk, base + 2, setA[0]);
+      fetch(setA[0]);
+      step(StepIndex<3>{}, chk, base + 3, setB[0]);
+      fetch(setB[0]);
+      step(StepIndex<4>{}, chk, base + 4, setA[0]);
+      fetch(setA[0]);
+      step(StepIndex<5>{}, chk, base + 5, setB[0]);
+    } else {
+      static_assert(D == 1 || D == 3, "prefetch batches of 1 or 3 rows");
+    }
+  };
+  // iterations whose six steps need no row test: every stage row (down to base - (S+E+1)) inside the grid, every
+  // output row (V': row - S, coarse F: row - S - 3) inside the chunk
+  const int fast_lo = r_begin + S + 3;
+  const int fast_hi = (r_end + S < row_hi ? r_end + S : row_hi) - 5;
+  for (int base = rstart; base < rstop; base += 6) {
+    if (base >= fast_lo && base < fast_hi) {
+      body(Checked<false>{}, base);
+      okbits = ~0u;
+    } else {
+      body(Checked<true>{}, base);
+    }
   }
 }
 

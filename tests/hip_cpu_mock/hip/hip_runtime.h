@@ -103,6 +103,9 @@ inline T __shfl(T v, int src, int width = 64) {
   return hipmock_shfl_from(v, (lane / width) * width + (src % width), true);
 }
 
+// the raw cross-lane read behind the shuffles: lane i receives `v` of lane (byte_addr / 4) % 64
+inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int v) { return hipmock_shfl_from(v, (byte_addr >> 2) & 63, true); }
+
 template <typename... KArgs, typename... Args>
 inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
   hipmock::run_grid(grid, block, [=]() { kernel(args...); });

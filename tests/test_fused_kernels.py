@@ -12,11 +12,12 @@ from oracle import structured as st
 SCALE = -1 / np.pi ** 2
 
 
-def _run(g, fused, kind, omega, what, nu, shift=0.7, k=1, gs=False, seed=0):
+def _run(g, fused, kind, omega, what, nu, shift=0.7, k=1, gs=False, seed=0, rows=0):
     op = laplacian_operator(g, "2d") * SCALE
     rng = np.random.RandomState(seed)
     p = Plan(op, 8, nvec=k)
     p.set_option(_lib.OPT_FUSED, fused)
+    p.set_option(_lib.OPT_FUSED_ROWS, rows)      # rows a wave marches over (0 = automatic); process-wide
     p.set_shifts(np.full(k, shift) + 0.1 * np.arange(k))
     for q in range(k):
         p.upload(0, _lib.SLOT_V, q, rng.rand(g * g))
@@ -41,6 +42,20 @@ def test_fused_equals_unfused(backend, g, kind, omega):
             assert rel_err(a, b) < 1e-12, (what, nu)
             if ca is not None:
                 assert rel_err(ca, cb) < 1e-12, (what, nu)        # the fused residual + restriction
+
+
+@pytest.mark.parametrize("kind,omega", [(_lib.WJACOBI, 2. / 3.), (_lib.GS_MC, 1.1)])
+def test_fused_chunk_lengths(backend, kind, omega):
+    """The marching loop has a checked body (chunk ends, grid boundary) and an unchecked steady-state one; short
+    chunks run only the first, long ones mostly the second.  Every chunk length gives the same cycle."""
+    ref, cref = _run(256, 0, kind, omega, "vcycle", 2)
+    try:
+        for rows in (6, 22, 64, 256):
+            a, ca = _run(256, 1, kind, omega, "vcycle", 2, rows=rows)
+            assert rel_err(a, ref) < 1e-12, rows
+            assert rel_err(ca, cref) < 1e-12, rows
+    finally:
+        _run(16, 1, kind, omega, "smooth", 1, rows=0)     # back to automatic
 
 
 def test_fused_multi_vector_cycle(backend):
