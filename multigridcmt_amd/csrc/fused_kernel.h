@@ -635,17 +635,36 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
       static_assert(D == 1 || D == 3, "prefetch batches of 1 or 3 rows");
     }
   };
-  // iterations whose six steps need no row test: every stage row (down to base - (S+E+1)) inside the grid, every
-  // output row (V': row - S, coarse F: row - S - 3) inside the chunk
+  // Iterations whose six steps need no row test: every stage row (down to base - (S+E+1)) inside the grid, every
+  // output row (V': row - S, coarse F: row - S - 3) inside the chunk.  They form the middle of the march and run
+  // in a loop of their own (an `if` inside one loop would make the two bodies meet at the loop latch, where the
+  // compiler then copies the whole register state and drains the prefetch); the checked body serves the few
+  // iterations before and after, the outer two-trip loop only exists so that its code is emitted once.
+  constexpr bool kFastBody = OP::kRowValues == 0;  // (the general operator's body is too long to have twice)
   const int fast_lo = r_begin + S + 3;
   const int fast_hi = (r_end + S < row_hi ? r_end + S : row_hi) - 5;
-  for (int base = rstart; base < rstop; base += 6) {
-    if (base >= fast_lo && base < fast_hi) {
-      body(Checked<false>{}, base);
-      okbits = ~0u;
-    } else {
-      body(Checked<true>{}, base);
+  int base = rstart;
+  if constexpr (kFastBody) {
+#pragma nounroll
+    for (int phase = 0; phase < 2; ++phase) {
+      int stop = rstop;
+      if (phase == 0) {
+        stop = rstart + ((fast_lo - rstart + 5) / 6) * 6;  // first loop position at or after fast_lo
+        if (stop > rstop) stop = rstop;
+      }
+#pragma nounroll
+      for (; base < stop; base += 6) body(Checked<true>{}, base);
+      if (phase == 0) {
+#pragma nounroll
+        for (; base < fast_hi; base += 6) {
+          body(Checked<false>{}, base);
+          okbits = ~0u;  // all of these rows were inside the grid
+        }
+      }
     }
+  } else {
+#pragma nounroll
+    for (; base < rstop; base += 6) body(Checked<true>{}, base);
   }
 }
 
