@@ -278,12 +278,23 @@ struct FusedShape {
   static constexpr int E = RESTRICT ? 1 : 0;
   // Lateral overlap of neighbouring windows.  Values go stale one column per stage from the window edges inwards
   // (plus one for an interpolated correction, plus two for the restriction), so S + 2 columns would do; the overlap
-  // is a fixed 8 columns instead, because then every wave STORES 112 columns = seven whole, 128-byte-aligned cache
-  // lines.  Measured with the access-pattern probe (mgcmt_bandwidth_probe kinds 5 / 8): windows whose stores start
-  // and end inside cache lines run a 2-read-1-write stream at 4.2 TB/s, line-aligned ones at 5.5 TB/s.
-  static constexpr int halo = 8;
+  // is a fixed 8 columns instead (16 for the passes with more than six stages), because then every wave STORES 112
+  // (96) columns = seven (six) whole, 128-byte-aligned cache lines.  Measured with the access-pattern probe
+  // (mgcmt_bandwidth_probe kinds 5 / 8): windows whose stores start and end inside cache lines run a
+  // 2-read-1-write stream at 4.2 TB/s, line-aligned ones at 5.5 TB/s.
+  static constexpr int need = S + (RESTRICT ? 2 : (PROLONG ? 1 : 0));
+  static constexpr int halo = need <= 8 ? 8 : 16;
   static constexpr int wout = 128 - 2 * halo;
-  static_assert(S + (RESTRICT ? 2 : (PROLONG ? 1 : 0)) <= halo, "too many pipeline stages for the window overlap");
+  static_assert(need <= halo, "too many pipeline stages for the window overlap");
+  // The colour smoothers update in place: ONE rotating window of `body` rows serves all their stages (a stage only
+  // changes its own colour, and points of one colour are never neighbours, so reading a row that the same stage
+  // has already passed is harmless).  Weighted Jacobi needs every stage's input intact: one 3-row window per stage.
+  static constexpr bool inplace = KIND != kJacobi;
+  // ... except for the interpolated correction, which changes every colour of a row: the stages behind it run one
+  // row later (XL), so that the row is corrected after the last pre-correction stage has read it
+  static constexpr int XL = (inplace && SPRE > 0) ? 1 : 0;
+  static constexpr int body = (inplace && S + E + 2 + XL > 6) ? 12 : 6;  // marching steps per loop iteration
+  static_assert(!inplace || S + E + 2 + XL <= body, "in-place window too short");
 };
 
 // kZeroIn: the error equation on a coarser level starts from zero (MGCMTSolver.py:316).
@@ -300,7 +311,7 @@ struct FusedShape {
 //  * row/column indices are 32-bit (wave-uniform tests stay on the scalar unit), only row offsets are 64-bit and
 //    advance incrementally.
 constexpr int mod3(int x) { return ((x % 3) + 3) % 3; }
-constexpr int mod6(int x) { return ((x % 6) + 6) % 6; }
+constexpr int modn(int x, int n) { return ((x % n) + n) % n; }
 template <int N>
 struct StepIndex {
   static constexpr int value = N;
@@ -309,6 +320,14 @@ template <bool B>
 struct Checked {
   static constexpr bool value = B;
 };
+// f(StepIndex<T0>{}), ..., f(StepIndex<T0 + N - 1>{})
+template <int T0, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    f(StepIndex<T0>{});
+    static_for<T0 + 1, N - 1>(f);
+  }
+}
 
 template <class OP, int KIND, int NSWEEP, int FLAGS>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
@@ -319,10 +338,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   constexpr bool NINE = OP::kNine;
   constexpr int WN = NINE ? S + E : 1;  // windows that also keep the lateral neighbours
   constexpr int D = NINE ? kDepth9 : kDepth;  // rows per prefetch batch
-  static_assert(6 % D == 0 && (6 / D) % 2 == 0, "the six-step loop body must hold an even number of prefetch batches");
-  constexpr int FL = S + E + 1;               // delay of the right-hand side between its load and its last use
-  constexpr bool FRING = FL <= 6;             // short enough for a rotating file of six; otherwise a shifting one
-  constexpr int FN = FRING ? 6 : FL;
+  constexpr bool INPLACE = Shape::inplace;
+  constexpr int XL = Shape::XL;
+  constexpr int B = Shape::body;              // marching steps per loop iteration
+  static_assert(B % D == 0 && (B / D) % 2 == 0, "the loop body must hold an even number of prefetch batches");
+  constexpr int FL = S + E + 1 + XL;          // delay of the right-hand side between its load and its last use
+  constexpr bool FRING = FL <= B;             // short enough for a rotating file of B; otherwise a shifting one
+  constexpr int FN = FRING ? B : FL;
 
   // workgroup -> (column group, row chunk).  Blocks b and b+8 run on the same XCD (own L2): an XCD gets a
   // CONTIGUOUS range of column groups, so the half cache lines two neighbouring windows share (their 8-column
@@ -367,7 +389,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   const int r_begin = chunk * a.rows_per_chunk;
   const int r_end = r_begin + a.rows_per_chunk < nr ? r_begin + a.rows_per_chunk : nr;
   const int rstart = r_begin - (S + E);
-  const int rstop = r_end + S + 2 * E;  // rows [rstart, rstop) are read
+  const int rstop = r_end + S + XL + 2 * E;  // rows [rstart, rstop) are marched over
 
   auto row_ok = [&](int row) { return row >= row_lo && row < row_hi; };
 
@@ -418,24 +440,33 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   // stage windows: w[s] is the input of stage s+1; w[S] (RESTRICT) the input of the residual stage.  Three rows
   // each, rotating: at loop position T stage s finds the row above / the row it updates / the row below (just
   // arrived) in slots mod3(T-s+1) / mod3(T-s+2) / mod3(T-s).  wl / wr: values left of ja / right of ja+1.
-  double wa[S + E][3], wb[S + E][3], wl[WN][3], wr[WN][3];
+  constexpr int NW = INPLACE ? 1 : S + E, NWN = INPLACE ? 1 : WN;
+  double wa[NW][3], wb[NW][3], wl[NWN][3], wr[NWN][3];
   double fa[FN], fb[FN];
 #pragma unroll
-  for (int s = 0; s < S + E; ++s)
+  for (int s = 0; s < NW; ++s)
 #pragma unroll
     for (int r = 0; r < 3; ++r) wa[s][r] = wb[s][r] = 0.0;
 #pragma unroll
-  for (int s = 0; s < WN; ++s)
+  for (int s = 0; s < NWN; ++s)
 #pragma unroll
     for (int r = 0; r < 3; ++r) wl[s][r] = wr[s][r] = 0.0;
+  // the in-place window: row (row - k) lives in slot modn(T - k, B)
+  constexpr int NR = INPLACE ? B : 1, NRN = (INPLACE && NINE) ? B : 1;
+  double Wa[NR], Wb[NR], Wl[NRN], Wr[NRN];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) Wa[r] = Wb[r] = 0.0;
+#pragma unroll
+  for (int r = 0; r < NRN; ++r) Wl[r] = Wr[r] = 0.0;
 #pragma unroll
   for (int s = 0; s < FN; ++s) fa[s] = fb[s] = 0.0;
 
   // coarse correction values of the last SPRE+2 fine rows: er[k] belongs to fine row (row - k); el[k] is the
   // value of the lane to the left
-  double er[SPRE + 2], el[SPRE + 2];
+  constexpr int NE = SPRE + 2 + XL;
+  double er[NE], el[NE];
 #pragma unroll
-  for (int k = 0; k < SPRE + 2; ++k) er[k] = el[k] = 0.0;
+  for (int k = 0; k < NE; ++k) er[k] = el[k] = 0.0;
   if (PROLONG) {
     // coarse row of fine row rstart-1 (used when rstart is even); row (row_lo>>1)-1 is the halo row
     const int I = (rstart - 1) >> 1;
@@ -466,7 +497,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
 
     if (PROLONG) {
 #pragma unroll
-      for (int k = SPRE + 1; k > 0; --k) {
+      for (int k = NE - 1; k > 0; --k) {
         er[k] = er[k - 1];
         el[k] = el[k - 1];
       }
@@ -477,10 +508,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
     // (c[J-1] + c[J]) / 2; an even fine row takes the mean of coarse rows I-1 and I
     // (lag = row - r; the correction of a row outside the grid is built from zeros, so it needs no row test)
     auto correct = [&](int lag, double& va, double& vb) __attribute__((always_inline)) {
-      const double e_cur = er[SPRE], e_prev = er[SPRE + 1];
-      double ca = 0.5 * (el[SPRE] + e_cur), cb = e_cur;
+      const double e_cur = er[lag], e_prev = er[lag + 1];
+      double ca = 0.5 * (el[lag] + e_cur), cb = e_cur;
       if (((T - lag - (S + E)) & 1) == 0) {
-        ca = 0.5 * (0.5 * (el[SPRE + 1] + e_prev) + ca);
+        ca = 0.5 * (0.5 * (el[lag + 1] + e_prev) + ca);
         cb = 0.5 * (e_prev + cb);
       }
       const double m = (!CHK || ((okbits >> lag) & 1u)) ? lanemask : 0.0;
@@ -489,7 +520,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
     };
     if (PROLONG && SPRE == 0) correct(0, ina, inb);
 
-    // right-hand side of row (row - k): slot mod6(T - k) of the rotating file, or entry k of the shifting one
+    // right-hand side of row (row - k): slot modn(T - k, B) of the rotating file, or entry k of the shifting one
     if (FRING) {
       fa[T] = in.f.x;
       fb[T] = in.f.y;
@@ -503,160 +534,256 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
       fb[0] = in.f.y;
     }
 
-    double oa = ina, ob = inb;  // output of the previous stage = next input row
-#pragma unroll
-    for (int s = 0; s <= S; ++s) {
-      if (s == S && !RESTRICT) break;
-      // the window of stage s (s == S: the residual stage) takes the row the previous stage has just finished
-      const int sn = mod3(T - s), sa = mod3(T - s + 1), sc = mod3(T - s + 2);
-      wa[s][sn] = oa;
-      wb[s][sn] = ob;
-      const int sw = NINE ? s : 0;
+    if constexpr (INPLACE) {
+      // ---- colour smoothers: one rotating window, updated in place --------------------------------------------
+      constexpr int s0 = modn(T, B);
+      Wa[s0] = ina;
+      Wb[s0] = inb;
       if (NINE) {
-        wl[sw][sn] = lane_fetch(lane_up, ob);
-        wr[sw][sn] = lane_fetch(lane_dn, oa);
+        Wl[s0] = lane_fetch(lane_up, inb);
+        Wr[s0] = lane_fetch(lane_dn, ina);
       }
-      const int rs = row - (s + 1);  // the row this stage completes now
-      const double ca = wa[s][sc], cb = wb[s][sc];
-      const double fva = FRING ? fa[mod6(T - (s + 1))] : fa[s + 1], fvb = FRING ? fb[mod6(T - (s + 1))] : fb[s + 1];
-      // neighbourhood of column ja / ja+1, handed to the operator policy
-      auto eval_a = [&](double& off, double& dg, double& inv) __attribute__((always_inline)) {
-        if constexpr (NINE) {
-          const double n[3] = {wl[sw][sa], wa[s][sa], wb[s][sa]}, c[3] = {wl[sw][sc], ca, cb}, so[3] = {wl[sw][sn], wa[s][sn], wb[s][sn]};
-          op.template eval<0>(n, c, so, off, dg, inv);
-          if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<0>(c, off, dg, inv);
-        } else {
-          const double left = lane_fetch(lane_up, cb);
-          const double n[3] = {0.0, wa[s][sa], 0.0}, c[3] = {left, ca, cb}, so[3] = {0.0, wa[s][sn], 0.0};
-          op.template eval<0>(n, c, so, off, dg, inv);
-        }
-      };
-      auto eval_b = [&](double& off, double& dg, double& inv) __attribute__((always_inline)) {
-        if constexpr (NINE) {
-          const double n[3] = {wa[s][sa], wb[s][sa], wr[sw][sa]}, c[3] = {ca, cb, wr[sw][sc]}, so[3] = {wa[s][sn], wb[s][sn], wr[sw][sn]};
-          op.template eval<1>(n, c, so, off, dg, inv);
-          if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<1>(c, off, dg, inv);
-        } else {
-          const double right = lane_fetch(lane_dn, ca);
-          const double n[3] = {0.0, wb[s][sa], 0.0}, c[3] = {ca, cb, right}, so[3] = {0.0, wb[s][sn], 0.0};
-          op.template eval<1>(n, c, so, off, dg, inv);
-        }
-      };
-
-      if (s < S) {
-        const int rs_par = (T - (s + 1) - (S + E)) & 1;  // parity of rs
-        bool upd_a = true, upd_b = true;
-        if (KIND == kRedBlack) {
-          const bool red = (s & 1) == 0;
-          const bool row_odd = rs_par != 0;
-          upd_a = red == row_odd;  // column ja is even: it is red ((i+j) odd) iff the row is odd
-          upd_b = !upd_a;
-        } else if (KIND == kFourColour) {
-          // colours (i%2, j%2) in the order (0,1),(1,0),(0,0),(1,1)
-          const int c = s & 3;
-          const int cra = (c == 1 || c == 3) ? 1 : 0, ccb = (c == 0 || c == 3) ? 1 : 0;
-          const bool row_on = rs_par == cra;
-          upd_a = row_on && ccb == 0;
-          upd_b = row_on && ccb == 1;
-        }
-        double na = ca, nb = cb;
-        // wave-uniform; outside the grid (a few steps of the first and last chunks) the value stays zero
-        if ((upd_a || upd_b) && (!CHK || ((okbits >> (s + 1)) & 1u) != 0)) {
-          op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
-          if (upd_a) {
-            double off, dg, inv;
-            eval_a(off, dg, inv);
-            na = fma(omega, (fva - fma(dg, ca, off)) * inv, ca);
+#pragma unroll
+      for (int s = 0; s <= S; ++s) {
+        if (s == S && !RESTRICT) break;
+        const int lag = s + 1 + ((XL > 0 && s >= SPRE) ? XL : 0);  // this stage works on row (row - lag)
+        const int cs = modn(T - lag + 1, B), cc = modn(T - lag, B), cn = modn(T - lag - 1, B);  // rows below / own / above
+        const int cl = NINE ? cc : 0, nl = NINE ? cn : 0, sl = NINE ? cs : 0;
+        const int rs = row - lag;
+        const double ca = Wa[cc], cb = Wb[cc];
+        const double fva = FRING ? fa[modn(T - lag, B)] : fa[lag], fvb = FRING ? fb[modn(T - lag, B)] : fb[lag];
+        auto eval_a = [&](double& off, double& dg, double& inv) __attribute__((always_inline)) {
+          if constexpr (NINE) {
+            const double n[3] = {Wl[nl], Wa[cn], Wb[cn]}, c[3] = {Wl[cl], ca, cb}, so[3] = {Wl[sl], Wa[cs], Wb[cs]};
+            op.template eval<0>(n, c, so, off, dg, inv);
+            if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<0>(c, off, dg, inv);
+          } else {
+            const double left = lane_fetch(lane_up, cb);
+            const double n[3] = {0.0, Wa[cn], 0.0}, c[3] = {left, ca, cb}, so[3] = {0.0, Wa[cs], 0.0};
+            op.template eval<0>(n, c, so, off, dg, inv);
           }
-          if (upd_b) {
-            double off, dg, inv;
-            eval_b(off, dg, inv);
-            nb = fma(omega, (fvb - fma(dg, cb, off)) * inv, cb);
+        };
+        auto eval_b = [&](double& off, double& dg, double& inv) __attribute__((always_inline)) {
+          if constexpr (NINE) {
+            const double n[3] = {Wa[cn], Wb[cn], Wr[nl]}, c[3] = {ca, cb, Wr[cl]}, so[3] = {Wa[cs], Wb[cs], Wr[sl]};
+            op.template eval<1>(n, c, so, off, dg, inv);
+            if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<1>(c, off, dg, inv);
+          } else {
+            const double right = lane_fetch(lane_dn, ca);
+            const double n[3] = {0.0, Wb[cn], 0.0}, c[3] = {ca, cb, right}, so[3] = {0.0, Wb[cs], 0.0};
+            op.template eval<1>(n, c, so, off, dg, inv);
           }
-        }
-        oa = na;
-        ob = nb;
-        if (PROLONG && SPRE > 0 && s == SPRE - 1) correct(s + 1, oa, ob);  // the recomputed pre-smoothing ends here
-        if (s == S - 1) {
-          const int rout = row - S;
-          if (STORE_V && col_out && (!CHK || (rout >= r_begin && rout < r_end))) store2_stream(vout + (long)rout * nc + ja, oa, ob);
-        }
-      } else {
-        // residual of row rs and its full-weighting restriction
-        double ra = 0.0, rb = 0.0;
-        if (!CHK || ((okbits >> (s + 1)) & 1u) != 0) {
-          op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
-          double offa, offb, dga, dgb, inva, invb;
-          eval_a(offa, dga, inva);
-          eval_b(offb, dgb, invb);
-          ra = lanemask * (fva - fma(dga, ca, offa));
-          rb = lanemask * (fvb - fma(dgb, cb, offb));
-        }
-        const double rnext = lane_fetch(lane_dn, ra);  // residual at column ja + 2
-        const double h = 0.25 * ra + 0.5 * rb + 0.25 * rnext;
-        if (((T - (s + 1) - (S + E)) & 1) == 0) {
-          const int I = (rs >> 1) - 1;  // coarse row closed by fine row rs = 2I + 2
-          if (col_out && ccol_in && (!CHK || (2 * I >= r_begin && 2 * I < r_end))) rc[I * cnc + jc] = racc + 0.25 * h;
-          racc = 0.25 * h;
+        };
+        if (s < S) {
+          const int rs_par = (T - lag - (S + E)) & 1;  // parity of rs
+          bool upd_a, upd_b;
+          if (KIND == kRedBlack) {
+            const bool red = (s & 1) == 0;
+            upd_a = red == (rs_par != 0);  // column ja is even: it is red ((i+j) odd) iff the row is odd
+            upd_b = !upd_a;
+          } else {
+            // colours (i%2, j%2) in the order (0,1),(1,0),(0,0),(1,1)
+            const int c = s & 3;
+            const int cra = (c == 1 || c == 3) ? 1 : 0, ccb = (c == 0 || c == 3) ? 1 : 0;
+            const bool row_on = rs_par == cra;
+            upd_a = row_on && ccb == 0;
+            upd_b = row_on && ccb == 1;
+          }
+          // wave-uniform; outside the grid (a few steps of the first and last chunks) the value stays zero
+          if ((upd_a || upd_b) && (!CHK || ((okbits >> lag) & 1u) != 0)) {
+            op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
+            if (upd_a) {
+              double off, dg, inv;
+              eval_a(off, dg, inv);
+              const double na = fma(omega, (fva - fma(dg, ca, off)) * inv, ca);
+              Wa[cc] = na;
+              if (NINE) Wr[cl] = lane_fetch(lane_dn, na);
+            }
+            if (upd_b) {
+              double off, dg, inv;
+              eval_b(off, dg, inv);
+              const double nb = fma(omega, (fvb - fma(dg, cb, off)) * inv, cb);
+              Wb[cc] = nb;
+              if (NINE) Wl[cl] = lane_fetch(lane_up, nb);
+            }
+          }
+          if (PROLONG && SPRE > 0 && s == SPRE - 1) {
+            // the recomputed pre-smoothing ends here: correct the row ABOVE the one just finished (nothing before
+            // the correction reads it again)
+            const int ck = modn(T - (lag + 1), B), ckl = NINE ? ck : 0;
+            correct(lag + 1, Wa[ck], Wb[ck]);
+            if (NINE) {
+              Wl[ckl] = lane_fetch(lane_up, Wb[ck]);
+              Wr[ckl] = lane_fetch(lane_dn, Wa[ck]);
+            }
+          }
+          if (s == S - 1) {
+            const int rout = rs;
+            if (STORE_V && col_out && (!CHK || (rout >= r_begin && rout < r_end))) store2_stream(vout + (long)rout * nc + ja, Wa[cc], Wb[cc]);
+          }
         } else {
-          racc += 0.5 * h;
+          // residual of row rs and its full-weighting restriction
+          double ra = 0.0, rb = 0.0;
+          if (!CHK || ((okbits >> lag) & 1u) != 0) {
+            op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
+            double offa, offb, dga, dgb, inva, invb;
+            eval_a(offa, dga, inva);
+            eval_b(offb, dgb, invb);
+            ra = lanemask * (fva - fma(dga, ca, offa));
+            rb = lanemask * (fvb - fma(dgb, cb, offb));
+          }
+          const double rnext = lane_fetch(lane_dn, ra);  // residual at column ja + 2
+          const double h = 0.25 * ra + 0.5 * rb + 0.25 * rnext;
+          if (((T - lag - (S + E)) & 1) == 0) {
+            const int I = (rs >> 1) - 1;  // coarse row closed by fine row rs = 2I + 2
+            if (col_out && ccol_in && (!CHK || (2 * I >= r_begin && 2 * I < r_end))) rc[I * cnc + jc] = racc + 0.25 * h;
+            racc = 0.25 * h;
+          } else {
+            racc += 0.5 * h;
+          }
         }
       }
-    }
-  };
-
-  // Six steps per iteration in 6/D batches: fetch a whole set, then process the other one.
-  auto body = [&](auto chk, const int base) __attribute__((always_inline)) {
-    if constexpr (D == 3) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) fetch(setB[u]);
-      step(StepIndex<0>{}, chk, base + 0, setA[0]);
-      step(StepIndex<1>{}, chk, base + 1, setA[1]);
-      step(StepIndex<2>{}, chk, base + 2, setA[2]);
-#pragma unroll
-      for (int u = 0; u < 3; ++u) fetch(setA[u]);
-      step(StepIndex<3>{}, chk, base + 3, setB[0]);
-      step(StepIndex<4>{}, chk, base + 4, setB[1]);
-      step(StepIndex<5>{}, chk, base + 5, setB[2]);
-    } else if constexpr (D == 1) {
-      fetch(setB[0]);
-      step(StepIndex<0>{}, chk, base + 0, setA[0]);
-      fetch(setA[0]);
-      step(StepIndex<1>{}, chk, base + 1, setB[0]);
-      fetch(setB[0]);
-      step(StepIndex<2>{}, chk, base + 2, setA[0]);
-      fetch(setA[0]);
-      step(StepIndex<3>{}, chk, base + 3, setB[0]);
-      fetch(setB[0]);
-      step(StepIndex<4>{}, chk, base + 4, setA[0]);
-      fetch(setA[0]);
-      step(StepIndex<5>{}, chk, base + 5, setB[0]);
     } else {
-      static_assert(D == 1 || D == 3, "prefetch batches of 1 or 3 rows");
+      // ---- weighted Jacobi: a pipeline of stages, each with its own three-row window ------------------------------
+      double oa = ina, ob = inb;  // output of the previous stage = next input row
+  #pragma unroll
+      for (int s = 0; s <= S; ++s) {
+        if (s == S && !RESTRICT) break;
+        // the window of stage s (s == S: the residual stage) takes the row the previous stage has just finished
+        const int sn = mod3(T - s), sa = mod3(T - s + 1), sc = mod3(T - s + 2);
+        wa[s][sn] = oa;
+        wb[s][sn] = ob;
+        const int sw = NINE ? s : 0;
+        if (NINE) {
+          wl[sw][sn] = lane_fetch(lane_up, ob);
+          wr[sw][sn] = lane_fetch(lane_dn, oa);
+        }
+        const int rs = row - (s + 1);  // the row this stage completes now
+        const double ca = wa[s][sc], cb = wb[s][sc];
+        const double fva = FRING ? fa[modn(T - (s + 1), B)] : fa[s + 1], fvb = FRING ? fb[modn(T - (s + 1), B)] : fb[s + 1];
+        // neighbourhood of column ja / ja+1, handed to the operator policy
+        auto eval_a = [&](double& off, double& dg, double& inv) __attribute__((always_inline)) {
+          if constexpr (NINE) {
+            const double n[3] = {wl[sw][sa], wa[s][sa], wb[s][sa]}, c[3] = {wl[sw][sc], ca, cb}, so[3] = {wl[sw][sn], wa[s][sn], wb[s][sn]};
+            op.template eval<0>(n, c, so, off, dg, inv);
+            if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<0>(c, off, dg, inv);
+          } else {
+            const double left = lane_fetch(lane_up, cb);
+            const double n[3] = {0.0, wa[s][sa], 0.0}, c[3] = {left, ca, cb}, so[3] = {0.0, wa[s][sn], 0.0};
+            op.template eval<0>(n, c, so, off, dg, inv);
+          }
+        };
+        auto eval_b = [&](double& off, double& dg, double& inv) __attribute__((always_inline)) {
+          if constexpr (NINE) {
+            const double n[3] = {wa[s][sa], wb[s][sa], wr[sw][sa]}, c[3] = {ca, cb, wr[sw][sc]}, so[3] = {wa[s][sn], wb[s][sn], wr[sw][sn]};
+            op.template eval<1>(n, c, so, off, dg, inv);
+            if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<1>(c, off, dg, inv);
+          } else {
+            const double right = lane_fetch(lane_dn, ca);
+            const double n[3] = {0.0, wb[s][sa], 0.0}, c[3] = {ca, cb, right}, so[3] = {0.0, wb[s][sn], 0.0};
+            op.template eval<1>(n, c, so, off, dg, inv);
+          }
+        };
+
+        if (s < S) {
+          const int rs_par = (T - (s + 1) - (S + E)) & 1;  // parity of rs
+          bool upd_a = true, upd_b = true;
+          if (KIND == kRedBlack) {
+            const bool red = (s & 1) == 0;
+            const bool row_odd = rs_par != 0;
+            upd_a = red == row_odd;  // column ja is even: it is red ((i+j) odd) iff the row is odd
+            upd_b = !upd_a;
+          } else if (KIND == kFourColour) {
+            // colours (i%2, j%2) in the order (0,1),(1,0),(0,0),(1,1)
+            const int c = s & 3;
+            const int cra = (c == 1 || c == 3) ? 1 : 0, ccb = (c == 0 || c == 3) ? 1 : 0;
+            const bool row_on = rs_par == cra;
+            upd_a = row_on && ccb == 0;
+            upd_b = row_on && ccb == 1;
+          }
+          double na = ca, nb = cb;
+          // wave-uniform; outside the grid (a few steps of the first and last chunks) the value stays zero
+          if ((upd_a || upd_b) && (!CHK || ((okbits >> (s + 1)) & 1u) != 0)) {
+            op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
+            if (upd_a) {
+              double off, dg, inv;
+              eval_a(off, dg, inv);
+              na = fma(omega, (fva - fma(dg, ca, off)) * inv, ca);
+            }
+            if (upd_b) {
+              double off, dg, inv;
+              eval_b(off, dg, inv);
+              nb = fma(omega, (fvb - fma(dg, cb, off)) * inv, cb);
+            }
+          }
+          oa = na;
+          ob = nb;
+          if (PROLONG && SPRE > 0 && s == SPRE - 1) correct(s + 1, oa, ob);  // the recomputed pre-smoothing ends here
+          if (s == S - 1) {
+            const int rout = row - S;
+            if (STORE_V && col_out && (!CHK || (rout >= r_begin && rout < r_end))) store2_stream(vout + (long)rout * nc + ja, oa, ob);
+          }
+        } else {
+          // residual of row rs and its full-weighting restriction
+          double ra = 0.0, rb = 0.0;
+          if (!CHK || ((okbits >> (s + 1)) & 1u) != 0) {
+            op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
+            double offa, offb, dga, dgb, inva, invb;
+            eval_a(offa, dga, inva);
+            eval_b(offb, dgb, invb);
+            ra = lanemask * (fva - fma(dga, ca, offa));
+            rb = lanemask * (fvb - fma(dgb, cb, offb));
+          }
+          const double rnext = lane_fetch(lane_dn, ra);  // residual at column ja + 2
+          const double h = 0.25 * ra + 0.5 * rb + 0.25 * rnext;
+          if (((T - (s + 1) - (S + E)) & 1) == 0) {
+            const int I = (rs >> 1) - 1;  // coarse row closed by fine row rs = 2I + 2
+            if (col_out && ccol_in && (!CHK || (2 * I >= r_begin && 2 * I < r_end))) rc[I * cnc + jc] = racc + 0.25 * h;
+            racc = 0.25 * h;
+          } else {
+            racc += 0.5 * h;
+          }
+        }
+      }
     }
   };
-  // Iterations whose six steps need no row test: every stage row (down to base - (S+E+1)) inside the grid, every
+
+  // B steps per iteration in B/D batches: fetch a whole set, then process the other one.
+  auto body = [&](auto chk, const int base) __attribute__((always_inline)) {
+    static_for<0, B / D>([&](auto g) __attribute__((always_inline)) {
+      constexpr int G = decltype(g)::value;
+      Row* cur = (G % 2 == 0) ? setA : setB;
+      Row* nxt = (G % 2 == 0) ? setB : setA;
+#pragma unroll
+      for (int u = 0; u < D; ++u) fetch(nxt[u]);
+      static_for<0, D>([&](auto u) __attribute__((always_inline)) {
+        constexpr int U = decltype(u)::value;
+        step(StepIndex<G * D + U>{}, chk, base + G * D + U, cur[U]);
+      });
+    });
+  };
+  // Iterations whose B steps need no row test: every stage row (down to base - (S+E+1)) inside the grid, every
   // output row (V': row - S, coarse F: row - S - 3) inside the chunk.  They form the middle of the march and run
   // in a loop of their own (an `if` inside one loop would make the two bodies meet at the loop latch, where the
   // compiler then copies the whole register state and drains the prefetch); the checked body serves the few
   // iterations before and after, the outer two-trip loop only exists so that its code is emitted once.
   constexpr bool kFastBody = OP::kRowValues == 0;  // (the general operator's body is too long to have twice)
-  const int fast_lo = r_begin + S + 3;
-  const int fast_hi = (r_end + S < row_hi ? r_end + S : row_hi) - 5;
+  const int fast_lo = r_begin + S + XL + 3;
+  const int fast_hi = (r_end + S + XL < row_hi ? r_end + S + XL : row_hi) - (B - 1);
   int base = rstart;
   if constexpr (kFastBody) {
 #pragma nounroll
     for (int phase = 0; phase < 2; ++phase) {
       int stop = rstop;
       if (phase == 0) {
-        stop = rstart + ((fast_lo - rstart + 5) / 6) * 6;  // first loop position at or after fast_lo
+        stop = rstart + ((fast_lo - rstart + B - 1) / B) * B;  // first loop position at or after fast_lo
         if (stop > rstop) stop = rstop;
       }
 #pragma nounroll
-      for (; base < stop; base += 6) body(Checked<true>{}, base);
+      for (; base < stop; base += B) body(Checked<true>{}, base);
       if (phase == 0) {
 #pragma nounroll
-        for (; base < fast_hi; base += 6) {
+        for (; base < fast_hi; base += B) {
           body(Checked<false>{}, base);
           okbits = ~0u;  // all of these rows were inside the grid
         }
@@ -664,7 +791,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
     }
   } else {
 #pragma nounroll
-    for (; base < rstop; base += 6) body(Checked<true>{}, base);
+    for (; base < rstop; base += B) body(Checked<true>{}, base);
   }
 }
 
@@ -733,8 +860,8 @@ void launch_variant(hipStream_t s, const FusedArgs& a, int flags, int k) {
       case kProlong | kZeroIn | (1 << kPreShift): return launch_one<OP, KIND, NSWEEP, kProlong | kZeroIn | (1 << kPreShift)>(s, a, k);
       default: break;
     }
-    // two recomputed sweeps: as long as all stages fit the window overlap (red-black: 2 + 2 sweeps are 8 stages + 1)
-    if constexpr (stages_of(KIND, 2) + stages_of(KIND, NSWEEP) + 1 <= 8) {
+    // two recomputed sweeps: as long as all stages fit the (wide) window overlap
+    if constexpr (stages_of(KIND, 2) + stages_of(KIND, NSWEEP) + 1 <= 16) {
       switch (flags) {
         case kProlong | (2 << kPreShift): return launch_one<OP, KIND, NSWEEP, kProlong | (2 << kPreShift)>(s, a, k);
         case kProlong | kZeroIn | (2 << kPreShift): return launch_one<OP, KIND, NSWEEP, kProlong | kZeroIn | (2 << kPreShift)>(s, a, k);

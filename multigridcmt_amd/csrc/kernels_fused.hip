@@ -29,15 +29,17 @@ bool fused_supported(const KGrid& g, const KOp& op) {
   return g.coarsen_rows && g.nr >= 4 && g.nc >= kFusedMinCols && (g.nc & 1) == 0 && (g.nr & 1) == 0 && (op.five_point || op.nine_const || op.nterms == 2 || op.nterms == 3);
 }
 
-// sweeps one pass can fuse: a 9-point four-colour sweep is already four pipeline stages
-int fused_max_sweeps(const KOp& op, int multicolour) { return (!op.five_point && multicolour) ? 1 : 2; }
+// sweeps one pass can fuse.  A 9-point four-colour sweep is four stages: two of them plus the restriction read nine
+// rows above the chunk, one more than a strip's MGCMT_HALO_ROWS, so strips (sharded levels) fuse one.
+int fused_max_sweeps(const KOp& op, int multicolour, bool strip) { return (!op.five_point && multicolour && strip) ? 1 : 2; }
 
 // sweeps of pre-smoothing an up-leg pass with `nsweep` post-smoothing sweeps can recompute in front of the
-// correction (0: none): all stages plus the correction must fit the 8-column window overlap
+// correction (0: none): all stages plus the correction must fit the window overlap (16 columns at most) and
+// the eight halo rows of a strip
 int fused_max_recompute(const KOp& op, int multicolour, int nsweep) {
   if (!op.five_point && multicolour) return 0;                  // four-colour sweeps: four stages each
   const int per_sweep = multicolour ? 2 : 1;
-  int n = (8 - 1 - per_sweep * nsweep) / per_sweep;
+  int n = (8 - per_sweep * nsweep) / per_sweep;
   return n < 0 ? 0 : (n > 2 ? 2 : n);
 }
 

@@ -6,7 +6,8 @@ namespace mgcmt {
 void launch_fused_op9c(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k) {
   using namespace fused;
   if (multicolour) {
-    launch_variant<Op9c, kFourColour, 1>(s, a, flags, k);
+    if (nsweep == 1) launch_variant<Op9c, kFourColour, 1>(s, a, flags, k);
+    else launch_variant<Op9c, kFourColour, 2>(s, a, flags, k);
   } else {
     if (nsweep == 1) launch_variant<Op9c, kJacobi, 1>(s, a, flags, k);
     else launch_variant<Op9c, kJacobi, 2>(s, a, flags, k);

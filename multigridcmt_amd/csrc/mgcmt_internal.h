@@ -61,7 +61,7 @@ void launch_lex_sweep(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doub
 // residual+restrict last (coarse = right-hand side); mode & 4: vin is zero; mode & 8: vout is not written (mode 2);
 // npre: pre-smoothing sweeps recomputed in front of the correction (mode 1)
 bool fused_supported(const KGrid& g, const KOp& op);
-int fused_max_sweeps(const KOp& op, int multicolour);
+int fused_max_sweeps(const KOp& op, int multicolour, bool strip);
 int fused_max_recompute(const KOp& op, int multicolour, int nsweep);
 void fused_set_rows(long rows);  // tuning: rows per chunk, 0 = automatic
 void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,

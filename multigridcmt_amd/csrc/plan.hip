@@ -322,7 +322,7 @@ bool fused_level(const mgcmt_plan* p, int l, int kind) {
 }
 
 int pass_sweeps(const mgcmt_plan* p, int l, int kind, int left) {
-  const int cap = fused_max_sweeps(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0);
+  const int cap = fused_max_sweeps(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0, p->levels[l].nr != p->levels[l].gr);
   return left < cap ? left : cap;
 }
 
