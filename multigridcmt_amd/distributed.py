@@ -44,6 +44,9 @@ class ShardedPlan:
                 "libmgcmt_hip.so: each brings a HIP runtime and only the first one loaded can open the device.")
         self.rank, self.world, self.on_gpu = rank, world, on_gpu
         self.device = device
+        # gloo moves host memory only: with device-resident strips (rehearsing several ranks on one GPU, or a box
+        # without RCCL) every message is staged through a host tensor.  RCCL (backend "nccl") sends device memory.
+        self.stage_host = bool(on_gpu and dist.is_initialized() and dist.get_backend() == "gloo")
         if op.dimension != "2d":
             raise ValueError("only 2-D problems are sharded")
         g = op.g
@@ -106,40 +109,52 @@ class ShardedPlan:
         return flat[a:a + nrows * cols]
 
     # -- communication ------------------------------------------------------------------------------
+    def _run_p2p(self, sends, recvs):
+        """One batch of point-to-point operations: sends / recvs are lists of (tensor view, peer rank)."""
+        dist = self.dist
+        if not sends and not recvs:
+            return
+        if self.stage_host:
+            staged = [(view, self.torch.empty(view.shape, dtype=view.dtype, device="cpu")) for view, _ in recvs]
+            ops = [dist.P2POp(dist.isend, view.cpu(), peer) for view, peer in sends]
+            ops += [dist.P2POp(dist.irecv, host, peer) for (_, peer), (_, host) in zip(recvs, staged)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for view, host in staged:
+                view.copy_(host)
+            return
+        ops = [dist.P2POp(dist.isend, view, peer) for view, peer in sends] + [dist.P2POp(dist.irecv, view, peer) for view, peer in recvs]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
     def exchange_halo(self, *pairs):
         """Fill the halo rows of every (level, slot) in `pairs` with the neighbours' boundary rows (chain
         topology), all in ONE batch of point-to-point operations."""
-        dist, H = self.dist, HALO_ROWS
-        ops = []
+        H = HALO_ROWS
+        sends, recvs = [], []
         up, down = self.rank - 1, self.rank + 1
         for level, slot in pairs:
             rows = self.plan.shapes[level][0]
             if up >= 0:
-                ops.append(dist.P2POp(dist.isend, self.rows_view(self.plan, level, slot, 0, H), up))
-                ops.append(dist.P2POp(dist.irecv, self.rows_view(self.plan, level, slot, -H, H), up))
+                sends.append((self.rows_view(self.plan, level, slot, 0, H), up))
+                recvs.append((self.rows_view(self.plan, level, slot, -H, H), up))
             if down < self.world:
-                ops.append(dist.P2POp(dist.isend, self.rows_view(self.plan, level, slot, rows - H, H), down))
-                ops.append(dist.P2POp(dist.irecv, self.rows_view(self.plan, level, slot, rows, H), down))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+                sends.append((self.rows_view(self.plan, level, slot, rows - H, H), down))
+                recvs.append((self.rows_view(self.plan, level, slot, rows, H), down))
+        self._run_p2p(sends, recvs)
 
     def gather_to_root(self, level, slot, dst_slot):
         """Strips of (level, slot) -> rank 0's whole-grid level 0 of the coarse plan."""
-        dist = self.dist
         rows = self.plan.shapes[level][0]
         if self.rank == 0:
             self.rows_view(self.coarse, 0, dst_slot, 0, rows).copy_(self.rows_view(self.plan, level, slot, 0, rows))
-            ops = [dist.P2POp(dist.irecv, self.rows_view(self.coarse, 0, dst_slot, r * rows, rows), r) for r in range(1, self.world)]
+            self._run_p2p([], [(self.rows_view(self.coarse, 0, dst_slot, r * rows, rows), r) for r in range(1, self.world)])
         else:
-            ops = [dist.P2POp(dist.isend, self.rows_view(self.plan, level, slot, 0, rows), 0)]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            self._run_p2p([(self.rows_view(self.plan, level, slot, 0, rows), 0)], [])
 
     def scatter_from_root(self, level, slot, src_slot):
         """Rank 0's whole-grid vector -> strips of (level, slot) including the halo rows that exist."""
-        dist, H = self.dist, HALO_ROWS
+        H = HALO_ROWS
         rows = self.plan.shapes[level][0]
         total = rows * self.world
 
@@ -149,16 +164,14 @@ class ShardedPlan:
         if self.rank == 0:
             lo, hi = span(0)
             self.rows_view(self.plan, level, slot, lo, hi - lo).copy_(self.rows_view(self.coarse, 0, src_slot, lo, hi - lo))
-            ops = []
+            sends = []
             for r in range(1, self.world):
                 lo, hi = span(r)
-                ops.append(dist.P2POp(dist.isend, self.rows_view(self.coarse, 0, src_slot, lo, hi - lo), r))
+                sends.append((self.rows_view(self.coarse, 0, src_slot, lo, hi - lo), r))
+            self._run_p2p(sends, [])
         else:
             lo, hi = span(self.rank)
-            ops = [dist.P2POp(dist.irecv, self.rows_view(self.plan, level, slot, lo - self.rank * rows, hi - lo), 0)]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            self._run_p2p([], [(self.rows_view(self.plan, level, slot, lo - self.rank * rows, hi - lo), 0)])
 
     # -- data ---------------------------------------------------------------------------------------
     def set_shift(self, mu):
@@ -250,7 +263,8 @@ class ShardedPlan:
         P.apply(0, (SLOT_V, 0), (SLOT_T, 0), with_shift=True)
         P.axpy(0, -1.0, (SLOT_F, 0), (SLOT_T, 0))
         local = P.dot(0, (SLOT_T, 0), (SLOT_T, 0))
-        t = self.torch.tensor([local], dtype=self.torch.float64, device=("cuda:%d" % self.device) if self.on_gpu else "cpu")
+        t = self.torch.tensor([local], dtype=self.torch.float64,
+                              device=("cuda:%d" % self.device) if self.on_gpu and not self.stage_host else "cpu")
         self.dist.all_reduce(t)
         return float(t.item()) ** 0.5
 

@@ -87,6 +87,56 @@ def test_sharded_plan_single_rank_on_gpu(hip_only):
     assert "SHARDED_WORLD1_OK" in out.stdout
 
 
+@pytest.mark.parametrize("world,kind_name", [(2, "wjacobi"), (4, "rb")])
+def test_sharded_ranks_share_one_gpu(hip_only, tmp_path, world, kind_name):
+    """Several ranks on the box's ONE GPU (gloo group, halo rows staged through host memory): the HIP strip kernels
+    with real neighbours on both sides, the gather / scatter around the coarse problem and the recompute passes.
+    The result must be the single-plan cycle's.  (RCCL cannot put two ranks on one device; the device-to-device
+    exchange itself is exercised at world size 1 above and by the round driver's multi-GPU run.)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    g = 2048
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_gloo_gpu.py"), str(r), str(world), port, str(g),
+                               kind_name, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for pr in procs:
+        try:
+            outs.append(pr.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (pr, out) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0 and "SHARDED_GLOO_GPU_OK" in out, "rank %d: %s" % (r, out[-3000:])
+    got = np.concatenate([np.load(tmp_path / ("part%d.npy" % r)) for r in range(world)])
+    res, strip_levels = np.load(tmp_path / "res.npy")
+    assert strip_levels == 2
+    kind, omega = (_lib.WJACOBI, 2. / 3.) if kind_name == "wjacobi" else (_lib.GS_MC, 1.0)
+    rng = np.random.RandomState(9)
+    f, v0 = rng.rand(g * g), rng.rand(g * g)
+    p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
+    p.set_shifts([0.3])
+    p.upload(0, _lib.SLOT_F, 0, f)
+    p.upload(0, _lib.SLOT_V, 0, v0)
+    for _ in range(2):
+        p.vcycle(2, 2, kind, omega=omega, nu_coarse=2)
+    want = p.download(0, _lib.SLOT_V, 0)
+    p.apply(0, (_lib.SLOT_V, 0), (_lib.SLOT_T, 0), with_shift=True)
+    p.axpy(0, -1.0, (_lib.SLOT_F, 0), (_lib.SLOT_T, 0))
+    want_res = np.sqrt(p.dot(0, (_lib.SLOT_T, 0), (_lib.SLOT_T, 0)))
+    p.close()
+    assert rel_err(got, want) < 1e-12
+    assert abs(res - want_res) < 1e-9 * want_res
+
+
 @pytest.mark.parametrize("g,kind,omega,nu", [(1024, _lib.WJACOBI, 2. / 3., 2), (1024, _lib.GS_MC, 1.0, 3), (512, _lib.WJACOBI, 2. / 3., 1)])
 def test_graph_replay_equals_eager(hip_only, g, kind, omega, nu):
     """mgcmt_vcycle replays a captured HIP graph from its second call on; results must be those of eager launches,
