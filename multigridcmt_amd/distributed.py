@@ -4,8 +4,10 @@ Rank r owns rows [r*g/P, (r+1)*g/P) of every strip level.  Between
 ranks exchange MGCMT_HALO_ROWS halo rows of V (and once per level of F) with their chain neighbours through
 ``torch.distributed`` point-to-point calls — RCCL over xGMI on GPUs, gloo in the CPU tests — and the fused
 kernels recompute the few overlap rows redundantly, so one exchange serves a whole pass (two sweeps and a
-transfer).  Below the switch level the strips are gathered on rank 0, which runs the rest of the cycle on
-its own with ``mgcmt_vcycle`` and scatters the correction (with halo rows) back.  Weighted Jacobi and the
+transfer).  Below the switch level every rank holds the WHOLE coarse problem: one all-gather assembles the
+restricted residual on all ranks, each runs the rest of the cycle redundantly with ``mgcmt_vcycle`` (a captured
+HIP graph, identical arithmetic everywhere) and takes its own rows (with halo rows) of the correction — no rank
+waits for another one's coarse solve and nothing has to be sent back.  Weighted Jacobi and the
 multicolour Gauss-Seidel are order-independent, so the sharded cycle computes what the single-GPU cycle
 computes (tests/test_distributed.py); the lexicographic smoothers do not shard.
 
@@ -69,16 +71,14 @@ class ShardedPlan:
         self.plan = Plan(op, g >> ls, nvec=1, device=device, row_begin=self.row_begin, row_end=self.row_end,
                          strip_levels=ls + 1)
         self.g, self.switch = g, g >> ls
-        # rank 0 continues from the switch level on the whole grid
-        self.coarse = None
-        if rank == 0:
-            from .operators import StructuredOperator
-            terms = []
-            xf = self.plan.factors(ls, 0)
-            yf = self.plan.factors(ls, 1)
-            for m in range(xf.shape[0]):
-                terms.append((xf[m].copy(), yf[m].copy()))
-            self.coarse = Plan(StructuredOperator("2d", self.switch, terms), lowest, nvec=1, device=device)
+        # every rank continues from the switch level on the whole grid (redundantly)
+        from .operators import StructuredOperator
+        terms = []
+        xf = self.plan.factors(ls, 0)
+        yf = self.plan.factors(ls, 1)
+        for m in range(xf.shape[0]):
+            terms.append((xf[m].copy(), yf[m].copy()))
+        self.coarse = Plan(StructuredOperator("2d", self.switch, terms), lowest, nvec=1, device=device)
         self._views = {}
         self._fine_rhs_halo_valid = False
         self.use_recompute = True
@@ -143,41 +143,35 @@ class ShardedPlan:
                 recvs.append((self.rows_view(self.plan, level, slot, rows, H), down))
         self._run_p2p(sends, recvs)
 
-    def gather_to_root(self, level, slot, dst_slot):
-        """Strips of (level, slot) -> rank 0's whole-grid level 0 of the coarse plan."""
+    def gather_all(self, level, slot, dst_slot):
+        """Strips of (level, slot) -> the whole-grid level 0 of every rank's coarse plan (one all-gather)."""
+        dist = self.dist
         rows = self.plan.shapes[level][0]
-        if self.rank == 0:
-            self.rows_view(self.coarse, 0, dst_slot, 0, rows).copy_(self.rows_view(self.plan, level, slot, 0, rows))
-            self._run_p2p([], [(self.rows_view(self.coarse, 0, dst_slot, r * rows, rows), r) for r in range(1, self.world)])
+        mine = self.rows_view(self.plan, level, slot, 0, rows)
+        parts = [self.rows_view(self.coarse, 0, dst_slot, r * rows, rows) for r in range(self.world)]
+        if self.world == 1:
+            parts[0].copy_(mine)
+        elif self.stage_host:
+            host = [self.torch.empty(mine.shape, dtype=mine.dtype, device="cpu") for _ in range(self.world)]
+            dist.all_gather(host, mine.cpu())
+            for view, h in zip(parts, host):
+                view.copy_(h)
         else:
-            self._run_p2p([(self.rows_view(self.plan, level, slot, 0, rows), 0)], [])
+            dist.all_gather(parts, mine)
 
-    def scatter_from_root(self, level, slot, src_slot):
-        """Rank 0's whole-grid vector -> strips of (level, slot) including the halo rows that exist."""
+    def take_own_rows(self, level, slot, src_slot):
+        """This rank's rows of the coarse plan's whole-grid vector -> (level, slot), including the halo rows that
+        exist (a local copy)."""
         H = HALO_ROWS
         rows = self.plan.shapes[level][0]
         total = rows * self.world
-
-        def span(r):                                   # global rows [lo, hi) rank r needs, halos included
-            return max(r * rows - H, 0), min((r + 1) * rows + H, total)
-
-        if self.rank == 0:
-            lo, hi = span(0)
-            self.rows_view(self.plan, level, slot, lo, hi - lo).copy_(self.rows_view(self.coarse, 0, src_slot, lo, hi - lo))
-            sends = []
-            for r in range(1, self.world):
-                lo, hi = span(r)
-                sends.append((self.rows_view(self.coarse, 0, src_slot, lo, hi - lo), r))
-            self._run_p2p(sends, [])
-        else:
-            lo, hi = span(self.rank)
-            self._run_p2p([], [(self.rows_view(self.plan, level, slot, lo - self.rank * rows, hi - lo), 0)])
+        lo, hi = max(self.rank * rows - H, 0), min((self.rank + 1) * rows + H, total)
+        self.rows_view(self.plan, level, slot, lo - self.rank * rows, hi - lo).copy_(self.rows_view(self.coarse, 0, src_slot, lo, hi - lo))
 
     # -- data ---------------------------------------------------------------------------------------
     def set_shift(self, mu):
         self.plan.set_shifts([float(mu)])
-        if self.coarse is not None:
-            self.coarse.set_shifts([float(mu)])
+        self.coarse.set_shifts([float(mu)])
 
     def upload_local(self, slot, host_rows):
         """This rank's rows of a fine-level vector (host array of local_rows*g doubles)."""
@@ -237,11 +231,10 @@ class ShardedPlan:
                     mode |= 8
                     recompute[l], still_zero[l] = n, zero_in
                 P.fused_pass(l, kind, n, omega=omega, mode=mode | (4 if zero_in else 0))
-        # the coarse problem: gather, run the sub-cycle on rank 0, scatter the correction with its halo rows
-        self.gather_to_root(ls, SLOT_F, SLOT_F)
-        if self.rank == 0:
-            self.coarse.vcycle(nu_coarse, nu_coarse, kind, omega=omega, k=1, nu_coarse=nu_coarse, level=0, zero_start=True)
-        self.scatter_from_root(ls, SLOT_V, SLOT_V)
+        # the coarse problem: all-gather, the same sub-cycle on every rank, own rows of the correction with halo rows
+        self.gather_all(ls, SLOT_F, SLOT_F)
+        self.coarse.vcycle(nu_coarse, nu_coarse, kind, omega=omega, k=1, nu_coarse=nu_coarse, level=0, zero_start=True)
+        self.take_own_rows(ls, SLOT_V, SLOT_V)
         for l in range(ls - 1, -1, -1):
             nu = nu2 if l == 0 else nu_coarse
             passes = self._passes(l, kind, nu)
@@ -271,5 +264,4 @@ class ShardedPlan:
     def close(self):
         self._views.clear()
         self.plan.close()
-        if self.coarse is not None:
-            self.coarse.close()
+        self.coarse.close()
