@@ -31,7 +31,7 @@ for name, kind, omega in (("wjacobi", _lib.WJACOBI, 2. / 3.), ("rb", _lib.GS_MC,
         p.sync()
         out["vcycle_ms_%s_%s" % (name, "fused" if fused else "baseline")] = (time.perf_counter() - t) * 100
     p.set_option(_lib.OPT_FUSED, 1)
-    ms = p.time_smoother(0, kind, 2, omega, 10)
+    ms = p.time_smoother(0, kind, 2, omega, 10) / 10
     out["smooth2_ms_%s" % name] = ms
     out["smooth2_GBs_24B_%s" % name] = 2 * 24.0 * g * g / ms / 1e6
 p.close()
