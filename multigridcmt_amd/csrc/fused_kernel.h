@@ -103,14 +103,34 @@ __device__ __forceinline__ void store2_stream(double* p, double x, double y) {
 
 constexpr int round_even(int x) { return (x + 1) & ~1; }
 
-// value of `v` in the lane whose byte address (4 * lane) is given: the shuffles of the marching loop read the
-// neighbouring lanes through two precomputed addresses instead of recomputing them at every call
-__device__ __forceinline__ double lane_fetch(int byte_addr, double v) {
+// Neighbour-lane reads of the marching loop.  MGCMT_FUSED_DPP = 1: wave-wide DPP shifts (two v_mov_b32_dpp per
+// double, no LDS round trip; a lane without a neighbour reads zero).  = 0: ds_bpermute through two precomputed
+// lane addresses (a lane without a neighbour reads itself).  The two differ only in lanes 0 / 63, whose columns lie
+// in the window overlap and are never stored.
+#ifndef MGCMT_FUSED_DPP
+#define MGCMT_FUSED_DPP 1
+#endif
+__device__ __forceinline__ double lane_fetch_addr(int byte_addr, double v) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(unsigned)u);
   const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(unsigned)(u >> 32));
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+#if MGCMT_FUSED_DPP && defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL>
+__device__ __forceinline__ double lane_shift(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// value of the left neighbour (lane - 1): wave_shr:1; of the right neighbour (lane + 1): wave_shl:1
+#define MGCMT_FETCH_LEFT(addr, v) lane_shift<0x138>(v)
+#define MGCMT_FETCH_RIGHT(addr, v) lane_shift<0x130>(v)
+#else
+#define MGCMT_FETCH_LEFT(addr, v) lane_fetch_addr(addr, v)
+#define MGCMT_FETCH_RIGHT(addr, v) lane_fetch_addr(addr, v)
+#endif
 
 // Arithmetic note: multiply-adds are written as explicit fma() (fewer VALU issues; measured -10 % on a 4096^2
 // cycle) rather than left to -ffp-contract, so that every instantiation rounds identically: the "recompute instead
@@ -200,6 +220,19 @@ struct Op9c {
   }
 };
 
+// 1 / d for the variable-coefficient policy, where it is needed per point and stage: the hardware estimate refined
+// by two Newton steps (full double accuracy to the last bit or two) instead of the ~12-instruction IEEE division.
+__device__ __forceinline__ double fast_reciprocal(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / d;
+#endif
+}
+
 // general separable 9-point operator  sum_m X_m (x) Y_m  (variable coefficients: potentials, PotWellSolver.py:150-153
 // style wells): the lane keeps the column factors of its two columns in registers.  The row factors (3M numbers per
 // row, the same for every lane) travel with the prefetched rows — lane k < 3M loads value k of the row — and are
@@ -252,7 +285,7 @@ struct Op9 {
     }
     off = o;
     dg = dd - mu;
-    inv = 1.0 / dg;
+    inv = fast_reciprocal(dg);
   }
 };
 
@@ -471,7 +504,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
     // coarse row of fine row rstart-1 (used when rstart is even); row (row_lo>>1)-1 is the halo row
     const int I = (rstart - 1) >> 1;
     if (ccol_in && I >= crow_lo && I <= crow_hi) er[0] = ec[I * cnc + jc];
-    el[0] = lane_fetch(lane_up, er[0]);
+    el[0] = MGCMT_FETCH_LEFT(lane_up, er[0]);
   }
   double racc = 0.0;  // running full-weighting sum of the current coarse row (RESTRICT)
   unsigned okbits = 0;  // bit k: row (row - k) lies inside the grid (wave-uniform shift register)
@@ -502,7 +535,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
         el[k] = el[k - 1];
       }
       er[0] = in.e * (rok ? cmask : 0.0);
-      el[0] = lane_fetch(lane_up, er[0]);
+      el[0] = MGCMT_FETCH_LEFT(lane_up, er[0]);
     }
     // V += P e on fine row r (values va, vb of this lane's columns): odd fine column takes c[J], even takes
     // (c[J-1] + c[J]) / 2; an even fine row takes the mean of coarse rows I-1 and I
@@ -540,8 +573,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
       Wa[s0] = ina;
       Wb[s0] = inb;
       if (NINE) {
-        Wl[s0] = lane_fetch(lane_up, inb);
-        Wr[s0] = lane_fetch(lane_dn, ina);
+        Wl[s0] = MGCMT_FETCH_LEFT(lane_up, inb);
+        Wr[s0] = MGCMT_FETCH_RIGHT(lane_dn, ina);
       }
 #pragma unroll
       for (int s = 0; s <= S; ++s) {
@@ -558,7 +591,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
             op.template eval<0>(n, c, so, off, dg, inv);
             if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<0>(c, off, dg, inv);
           } else {
-            const double left = lane_fetch(lane_up, cb);
+            const double left = MGCMT_FETCH_LEFT(lane_up, cb);
             const double n[3] = {0.0, Wa[cn], 0.0}, c[3] = {left, ca, cb}, so[3] = {0.0, Wa[cs], 0.0};
             op.template eval<0>(n, c, so, off, dg, inv);
           }
@@ -569,7 +602,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
             op.template eval<1>(n, c, so, off, dg, inv);
             if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<1>(c, off, dg, inv);
           } else {
-            const double right = lane_fetch(lane_dn, ca);
+            const double right = MGCMT_FETCH_RIGHT(lane_dn, ca);
             const double n[3] = {0.0, Wb[cn], 0.0}, c[3] = {ca, cb, right}, so[3] = {0.0, Wb[cs], 0.0};
             op.template eval<1>(n, c, so, off, dg, inv);
           }
@@ -597,14 +630,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
               eval_a(off, dg, inv);
               const double na = fma(omega, (fva - fma(dg, ca, off)) * inv, ca);
               Wa[cc] = na;
-              if (NINE) Wr[cl] = lane_fetch(lane_dn, na);
+              if (NINE) Wr[cl] = MGCMT_FETCH_RIGHT(lane_dn, na);
             }
             if (upd_b) {
               double off, dg, inv;
               eval_b(off, dg, inv);
               const double nb = fma(omega, (fvb - fma(dg, cb, off)) * inv, cb);
               Wb[cc] = nb;
-              if (NINE) Wl[cl] = lane_fetch(lane_up, nb);
+              if (NINE) Wl[cl] = MGCMT_FETCH_LEFT(lane_up, nb);
             }
           }
           if (PROLONG && SPRE > 0 && s == SPRE - 1) {
@@ -613,8 +646,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
             const int ck = modn(T - (lag + 1), B), ckl = NINE ? ck : 0;
             correct(lag + 1, Wa[ck], Wb[ck]);
             if (NINE) {
-              Wl[ckl] = lane_fetch(lane_up, Wb[ck]);
-              Wr[ckl] = lane_fetch(lane_dn, Wa[ck]);
+              Wl[ckl] = MGCMT_FETCH_LEFT(lane_up, Wb[ck]);
+              Wr[ckl] = MGCMT_FETCH_RIGHT(lane_dn, Wa[ck]);
             }
           }
           if (s == S - 1) {
@@ -632,7 +665,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
             ra = lanemask * (fva - fma(dga, ca, offa));
             rb = lanemask * (fvb - fma(dgb, cb, offb));
           }
-          const double rnext = lane_fetch(lane_dn, ra);  // residual at column ja + 2
+          const double rnext = MGCMT_FETCH_RIGHT(lane_dn, ra);  // residual at column ja + 2
           const double h = 0.25 * ra + 0.5 * rb + 0.25 * rnext;
           if (((T - lag - (S + E)) & 1) == 0) {
             const int I = (rs >> 1) - 1;  // coarse row closed by fine row rs = 2I + 2
@@ -655,8 +688,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
         wb[s][sn] = ob;
         const int sw = NINE ? s : 0;
         if (NINE) {
-          wl[sw][sn] = lane_fetch(lane_up, ob);
-          wr[sw][sn] = lane_fetch(lane_dn, oa);
+          wl[sw][sn] = MGCMT_FETCH_LEFT(lane_up, ob);
+          wr[sw][sn] = MGCMT_FETCH_RIGHT(lane_dn, oa);
         }
         const int rs = row - (s + 1);  // the row this stage completes now
         const double ca = wa[s][sc], cb = wb[s][sc];
@@ -668,7 +701,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
             op.template eval<0>(n, c, so, off, dg, inv);
             if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<0>(c, off, dg, inv);
           } else {
-            const double left = lane_fetch(lane_up, cb);
+            const double left = MGCMT_FETCH_LEFT(lane_up, cb);
             const double n[3] = {0.0, wa[s][sa], 0.0}, c[3] = {left, ca, cb}, so[3] = {0.0, wa[s][sn], 0.0};
             op.template eval<0>(n, c, so, off, dg, inv);
           }
@@ -679,7 +712,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
             op.template eval<1>(n, c, so, off, dg, inv);
             if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<1>(c, off, dg, inv);
           } else {
-            const double right = lane_fetch(lane_dn, ca);
+            const double right = MGCMT_FETCH_RIGHT(lane_dn, ca);
             const double n[3] = {0.0, wb[s][sa], 0.0}, c[3] = {ca, cb, right}, so[3] = {0.0, wb[s][sn], 0.0};
             op.template eval<1>(n, c, so, off, dg, inv);
           }
@@ -734,7 +767,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
             ra = lanemask * (fva - fma(dga, ca, offa));
             rb = lanemask * (fvb - fma(dgb, cb, offb));
           }
-          const double rnext = lane_fetch(lane_dn, ra);  // residual at column ja + 2
+          const double rnext = MGCMT_FETCH_RIGHT(lane_dn, ra);  // residual at column ja + 2
           const double h = 0.25 * ra + 0.5 * rb + 0.25 * rnext;
           if (((T - (s + 1) - (S + E)) & 1) == 0) {
             const int I = (rs >> 1) - 1;  // coarse row closed by fine row rs = 2I + 2
@@ -767,7 +800,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   // in a loop of their own (an `if` inside one loop would make the two bodies meet at the loop latch, where the
   // compiler then copies the whole register state and drains the prefetch); the checked body serves the few
   // iterations before and after, the outer two-trip loop only exists so that its code is emitted once.
-  constexpr bool kFastBody = OP::kRowValues == 0;  // (the general operator's body is too long to have twice)
+  constexpr bool kFastBody = OP::kRowValues == 0 || B == 6;  // (the general operator's 12-step bodies are too long to have twice)
   const int fast_lo = r_begin + S + XL + 3;
   const int fast_hi = (r_end + S + XL < row_hi ? r_end + S + XL : row_hi) - (B - 1);
   int base = rstart;

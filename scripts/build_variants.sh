@@ -1,6 +1,5 @@
 set -e
 cd "$(dirname "$0")/../multigridcmt_amd/csrc"
-rm -rf ../../build/variants; mkdir -p ../../build/variants
-build() { name=$1; shift; make -s -j8 OUT=$PWD/../../build/variants/lib_$name.so OBJDIR=$PWD/../../build/variants/obj_$name "$@"; echo built $name; }
-build d1 EXTRA=-DMGCMT_FUSED_DEPTH=1
-build d9_3 EXTRA=-DMGCMT_FUSED_DEPTH9=3
+rm -rf ../../build/variants ../../variants; mkdir -p ../../build/variants ../../variants
+build() { name=$1; shift; make -s -j8 OUT=$PWD/../../variants/lib_$name.so OBJDIR=$PWD/../../build/variants/obj_$name "$@"; echo built $name; }
+build dpp EXTRA=-DMGCMT_FUSED_DPP=1

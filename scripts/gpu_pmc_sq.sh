@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $R/gpurun_out/pmc_${TAG}_${SM} -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --smoother $SM > $R/gpurun_out/pmc_${TAG}_${SM}.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc ${PMC_LIST:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES} --output-format csv -d $R/gpurun_out/pmc_${TAG}_${SM} -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --smoother $SM > $R/gpurun_out/pmc_${TAG}_${SM}.log 2>&1
 tail -3 $R/gpurun_out/pmc_${TAG}_${SM}.log
 python3 - $R/gpurun_out/pmc_${TAG}_${SM} <<'PY'
 import csv, glob, sys, collections

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from multigridcmt_amd import _lib
 from multigridcmt_amd import plan as planmod
 from multigridcmt_amd.operators import laplacian_operator
-libs = [_lib.DEFAULT_LIBRARY] + sorted(glob.glob(os.path.join(ROOT, "build", "variants", "lib_*.so")))
+libs = [_lib.DEFAULT_LIBRARY] + sorted(glob.glob(os.path.join(ROOT, "variants", "lib_*.so")))
 for path in libs:
     _lib.use_library(path)
     row = {"lib": os.path.basename(path)}

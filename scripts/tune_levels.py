@@ -7,7 +7,7 @@ from multigridcmt_amd import _lib
 from multigridcmt_amd import plan as planmod
 from multigridcmt_amd.operators import laplacian_operator
 g = 16384
-libs = [_lib.DEFAULT_LIBRARY] + sorted(glob.glob(os.path.join(ROOT, "build", "variants", "lib_*.so")))
+libs = [_lib.DEFAULT_LIBRARY] + sorted(glob.glob(os.path.join(ROOT, "variants", "lib_*.so")))
 for path in libs:
     _lib.use_library(path)
     p = planmod.Plan(laplacian_operator(g, "2d") * (-1 / np.pi ** 2), 8, nvec=1)

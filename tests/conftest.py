@@ -36,9 +36,10 @@ def bind_backend(kind):
         return
     plan.release_plans()
     if kind == "hip":
-        if not os.path.exists(_lib.DEFAULT_LIBRARY):
-            pytest.fail("libmgcmt_hip.so is not built — run __graft_entry__.build()")
-        _lib.use_library(_lib.DEFAULT_LIBRARY)
+        path = os.environ.get("MGCMT_TEST_LIBRARY", _lib.DEFAULT_LIBRARY)     # a tuning variant of the HIP library
+        if not os.path.exists(path):
+            pytest.fail("%s is not built — run __graft_entry__.build()" % path)
+        _lib.use_library(path)
         if _lib.device_count() < 1:
             pytest.fail("no HIP device visible")
     else:
