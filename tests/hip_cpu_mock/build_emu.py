@@ -24,7 +24,7 @@ def build(force=False):
     for src in srcs + [os.path.join(HERE, "hipmock_runtime.cpp")]:
         obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "c++", "-I", HERE,
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "c++", "-I", HERE,
                "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "multigridcmt_amd", "csrc"),
                "-c", src, "-o", obj]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
