@@ -56,7 +56,9 @@ class ShardedPlan:
             raise ValueError("world size must be a power of two dividing the grid")
         nlev_total = _log2(g // lowest) + 1
         if switch_grid is None:
-            switch_grid = max(2048, 64 * world)
+            # below this grid the cycle is cheaper run whole on every rank than as strips with two more exchanges per
+            # level: 2048^2 costs 0.2 ms, 4096^2 0.34 ms on one GPU, an exchange ~0.1 ms of enqueue + latency
+            switch_grid = max(2048, 512 * world)
         # strip levels: grids above the switch size; every strip must keep >= 2*HALO_ROWS rows and even bounds
         ls = 0
         while ls < nlev_total - 1 and (g >> ls) > switch_grid and ((g >> ls) // world) >= 4 * HALO_ROWS:
