@@ -97,6 +97,122 @@ __global__ void k_project_out(long n, const double* __restrict__ partials, int n
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) aj[i] -= c * q[i];
 }
 
+// One step of modified Gram-Schmidt (MGCMTProcessor.py:44-50) in ONE pass over the data.  u = column i after the
+// projections of the earlier steps; pin holds the per-block partial sums of <u, a_{i+t}>, t = 0..m (t = 0: <u,u>),
+// left by the previous step.  Per element: a_{i+t} -= (<u,a_{i+t}>/<u,u>) u for t = 1..m — the reference's
+// (<a,q>/<q,q>) q with q = u/|u|, written with the un-normalised u — then u /= |u|, and the partial sums of
+// <a'_{i+1}, a'_{i+1+t}> for the next step are accumulated on the way.  1 + 2m streams instead of the 5m of separate
+// dot / projection launches.  Sums are deterministic: fixed per-thread order, fixed tree, per-block partials.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+  return v;  // valid on lane 0
+}
+
+__global__ void __launch_bounds__(kRedThreads) k_mgs_step(long n, const double* __restrict__ pin, int nb_in, double* __restrict__ u, long stride,
+                                                          int m, double* __restrict__ pout) {
+  constexpr int kWaves = kRedThreads / 64;
+  __shared__ double s_sum[kMaxVec + 1];
+  __shared__ double s_part[kWaves][kMaxVec];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // S[t] = sum of result t's per-block partial sums: one wave per result, lane-strided then a shuffle tree (two
+  // barriers per launch in total — on small levels these launches are pure latency)
+  for (int t0 = 0; t0 <= m; t0 += kWaves) {  // (every wave makes the same number of trips)
+    const int t = t0 + wave;
+    double acc = 0.0;
+    if (t <= m)
+      for (int i = lane; i < nb_in; i += 64) acc += pin[(long)t * nb_in + i];
+    const double tot = wave_sum(acc);
+    if (lane == 0 && t <= m) s_sum[t] = tot;
+  }
+  __syncthreads();
+  const double s0 = s_sum[0];
+  const double nrm = sqrt(s0);
+  double c[kMaxVec], acc[kMaxVec];
+#pragma unroll
+  for (int t = 0; t < kMaxVec; ++t) {
+    c[t] = t < m ? s_sum[t + 1] / s0 : 0.0;
+    acc[t] = 0.0;
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const double ue = u[i];
+    double first = 0.0;
+#pragma unroll
+    for (int t = 0; t < kMaxVec; ++t) {
+      if (t < m) {  // uniform
+        double* at = u + (long)(t + 1) * stride;
+        const double a = at[i] - c[t] * ue;
+        at[i] = a;
+        if (t == 0) first = a;
+        acc[t] += first * a;
+      }
+    }
+    u[i] = ue / nrm;
+  }
+#pragma unroll
+  for (int t = 0; t < kMaxVec; ++t) {
+    if (t < m) {
+      const double tot = wave_sum(acc[t]);
+      if (lane == 0) s_part[wave][t] = tot;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < m) {
+    double tot = 0.0;
+    for (int w = 0; w < kWaves; ++w) tot += s_part[w][threadIdx.x];
+    pout[(long)threadIdx.x * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
+// The whole modified Gram-Schmidt of k short columns in ONE workgroup (levels of a few thousand points, where a
+// launch per column is pure latency): per column the inner products with all later columns, then the projections and
+// the normalisation, separated by workgroup barriers.  Same formulas as k_mgs_step.
+constexpr int kMgsSmallThreads = 1024;
+constexpr long kMgsSmallMaxN = 4096;
+__global__ void __launch_bounds__(kMgsSmallThreads) k_mgs_small(long n, double* __restrict__ a0, long stride, int k) {
+  constexpr int kWaves = kMgsSmallThreads / 64;
+  __shared__ double s_part[kWaves][kMaxVec];
+  __shared__ double s_sum[kMaxVec];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = 0; i < k; ++i) {
+    double* u = a0 + (long)i * stride;
+    const int m = k - 1 - i;
+    double acc[kMaxVec];
+#pragma unroll
+    for (int t = 0; t < kMaxVec; ++t) acc[t] = 0.0;
+    for (long e = threadIdx.x; e < n; e += kMgsSmallThreads) {
+      const double ue = u[e];
+#pragma unroll
+      for (int t = 0; t < kMaxVec; ++t)
+        if (t <= m) acc[t] += ue * u[(long)t * stride + e];
+    }
+#pragma unroll
+    for (int t = 0; t < kMaxVec; ++t) {
+      if (t <= m) {  // uniform
+        const double tot = wave_sum(acc[t]);
+        if (lane == 0) s_part[wave][t] = tot;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= m) {
+      double tot = 0.0;
+      for (int w = 0; w < kWaves; ++w) tot += s_part[w][threadIdx.x];
+      s_sum[threadIdx.x] = tot;
+    }
+    __syncthreads();
+    const double s0 = s_sum[0];
+    const double nrm = sqrt(s0);
+    for (long e = threadIdx.x; e < n; e += kMgsSmallThreads) {
+      const double ue = u[e];
+#pragma unroll
+      for (int t = 1; t < kMaxVec; ++t)
+        if (t <= m) u[(long)t * stride + e] -= (s_sum[t] / s0) * ue;
+      u[e] = ue / nrm;
+    }
+    __syncthreads();
+  }
+}
+
 // bandwidth probes (bench.py's empirical HBM ceilings): 16-byte accesses, grid-stride
 __global__ void k_probe_copy(long n2, const double2* __restrict__ a, double2* __restrict__ out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) out[i] = a[i];
@@ -206,6 +322,17 @@ void launch_scale_by_norm(hipStream_t s, long n, const double* partials, double*
 
 void launch_project_out(hipStream_t s, long n, const double* partials, const double* q, double* a_first, long astride, int nj) {
   hipLaunchKernelGGL(k_project_out, dim3(blocks_for(n), nj), dim3(256), 0, s, n, partials, reduce_blocks(n), q, a_first, astride);
+}
+
+bool mgs_small_fits(long n) { return n <= kMgsSmallMaxN; }
+
+void launch_mgs_small(hipStream_t s, long n, double* a0, long stride, int k) {
+  hipLaunchKernelGGL(k_mgs_small, dim3(1), dim3(kMgsSmallThreads), 0, s, n, a0, stride, k);
+}
+
+void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out) {
+  const int nb = reduce_blocks(n);
+  hipLaunchKernelGGL(k_mgs_step, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb, u, stride, m, partials_out);
 }
 
 void launch_dots(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, double* out) {

@@ -516,17 +516,19 @@ int gramschmidt_impl(mgcmt_plan* p, int l, int slot, int k, int modified, hipStr
   double* a0 = p->kvec(l, slot, 0).p;
   double* sc = p->d_scalars;
   if (modified) {
-    // MGCMTProcessor.py:44-50: q_i = a_i/|a_i|; a_j -= (<a_j,q_i>/<q_i,q_i>) q_i for j > i
-    // four launches per column: norm partials, scale, <q_i, .> partials for all later columns, projection of all of them
+    // MGCMTProcessor.py:44-50: q_i = a_i/|a_i|; a_j -= (<a_j,q_i>/<q_i,q_i>) q_i for j > i.
+    // One launch per column (k_mgs_step): it projects column i out of all later ones, normalises it and leaves the
+    // inner products the next column needs; the first set comes from one batched dot launch.
+    if (mgs_small_fits(n)) {
+      launch_mgs_small(s, n, a0, stride, k);  // short columns: everything in one workgroup
+      return post_launch();
+    }
+    double* pa = p->d_partials;
+    double* pb = p->d_partials + (long)(kMaxVec + 1) * 1024;
+    launch_dot_partials(s, n, a0, a0, stride, k, pa);  // <a_0, a_t>, t = 0..k-1
     for (int i = 0; i < k; ++i) {
-      double* ai = a0 + i * stride;
-      launch_dot_partials(s, n, ai, ai, 0, 1, p->d_partials);
-      launch_scale_by_norm(s, n, p->d_partials, ai);
-      if (i + 1 < k) {
-        // result 0 = <q_i,q_i>, result t = <q_i, a_{i+t}>
-        launch_dot_partials(s, n, ai, ai, stride, k - i, p->d_partials);
-        launch_project_out(s, n, p->d_partials, ai, ai + stride, stride, k - i - 1);
-      }
+      launch_mgs_step(s, n, pa, a0 + i * stride, stride, k - 1 - i, pb);
+      std::swap(pa, pb);
     }
     (void)sc;
   } else {
