@@ -46,4 +46,11 @@ for sm in KERNEL:
 for src, dst in (("bench_%s_default.json" % tag, "%s_bench_default_16384_wjacobi.json" % prefix), ("bench_%s_rb.json" % tag, "%s_bench_16384_rb.json" % prefix)):
     if os.path.exists(os.path.join(g, src)):
         shutil.copy(os.path.join(g, src), os.path.join(out, dst))
+# the bench line printed INSIDE the profiled run (same process as the kernel stats above)
+for sm in KERNEL:
+    log = os.path.join(g, "prof_%s_%s.log" % (tag, sm))
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith('{"metric"')]
+        if lines:
+            open(os.path.join(out, "%s_bench_under_rocprof_%s.json" % (prefix, sm)), "w").write(lines[-1])
 print(json.dumps(detail, indent=1))
