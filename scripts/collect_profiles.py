@@ -20,6 +20,7 @@ for sm, kname in KERNEL.items():
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         files = glob.glob(os.path.join(g, "pmc_%s_%s_%s" % (tag, sm, counter), "**", "*counter_collection.csv"), recursive=True)
+        files = sorted(files, key=os.path.getmtime)[-1:]          # the latest run only (a tag may have been used before)
         acc = []
         for f in files:
             for row in csv.DictReader(open(f)):
@@ -40,9 +41,9 @@ if table:
     json.dump(table, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     json.dump(detail, open(os.path.join(out, "%s_pmc_traffic_detail.json" % prefix), "w"), indent=1)
 for sm in KERNEL:
-    stats = glob.glob(os.path.join(g, "prof_%s_%s" % (tag, sm), "**", "*kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(os.path.join(g, "prof_%s_%s" % (tag, sm), "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], os.path.join(out, "%s_final_%s_%d_kernel_stats.csv" % (prefix, sm, n)))
+        shutil.copy(stats[-1], os.path.join(out, "%s_final_%s_%d_kernel_stats.csv" % (prefix, sm, n)))
 for src, dst in (("bench_%s_default.json" % tag, "%s_bench_default_16384_wjacobi.json" % prefix), ("bench_%s_rb.json" % tag, "%s_bench_16384_rb.json" % prefix)):
     if os.path.exists(os.path.join(g, src)):
         shutil.copy(os.path.join(g, src), os.path.join(out, dst))
