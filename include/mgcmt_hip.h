@@ -176,7 +176,7 @@ int mgcmt_time_smoother(mgcmt_plan* plan, int level, int kind, int nu, double om
  * the fused kernels' access pattern instead (128-column windows marching down `blocks` rows): read 1 stream (8 B),
  * read 2 (16 B), read 2 + write 1 (24 B); kinds 6/7/8 the same with overlapping, unaligned windows (124 of 128 kept),
  * 9/10/11 with the fused kernels' own geometry (112 of 128 kept: line-aligned stores, loads straddling half lines),
- * 12/13/14 with 96 of 128 kept (everything line-aligned); returns the average milliseconds per launch */
+ * 12/13/14 with 96 of 128 kept (everything line-aligned), 15/16/17 with 120 of 128 (64-byte-aligned); returns the average milliseconds per launch */
 int mgcmt_bandwidth_probe(mgcmt_plan* plan, int level, int kind, int blocks, int reps, double* ms_out, void* stream);
 
 #ifdef __cplusplus

@@ -316,7 +316,12 @@ struct FusedShape {
   // (mgcmt_bandwidth_probe kinds 5 / 8): windows whose stores start and end inside cache lines run a
   // 2-read-1-write stream at 4.2 TB/s, line-aligned ones at 5.5 TB/s.
   static constexpr int need = S + (RESTRICT ? 2 : (PROLONG ? 1 : 0));
-  static constexpr int halo = need <= 8 ? 8 : 16;
+  // A pass that does not store V' has no store alignment to protect: with few stages it overlaps by 4 columns only
+  // (probe kinds 10 / 16: two read streams run at 5.3 TB/s with 112 of 128 columns kept, 5.7 with 120).
+#ifndef MGCMT_FUSED_NARROW_NOSTORE
+#define MGCMT_FUSED_NARROW_NOSTORE 1
+#endif
+  static constexpr int halo = (MGCMT_FUSED_NARROW_NOSTORE && (FLAGS & kNoStore) != 0 && need <= 4) ? 4 : (need <= 8 ? 8 : 16);
   static constexpr int wout = 128 - 2 * halo;
   static_assert(need <= halo, "too many pipeline stages for the window overlap");
   // The colour smoothers update in place: ONE rotating window of `body` rows serves all their stages (a stage only

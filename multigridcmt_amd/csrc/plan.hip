@@ -1087,7 +1087,7 @@ int mgcmt_time_smoother(mgcmt_plan* p, int l, int kind, int nu, double omega, in
 
 int mgcmt_bandwidth_probe(mgcmt_plan* p, int l, int kind, int blocks, int reps, double* ms_out, void* stream) {
   MG_TRY(check_level(p, l));
-  if (!ms_out || reps < 1 || blocks < 1 || kind < 0 || kind > 14) return fail(MGCMT_ERR_INVALID, "bad arguments");
+  if (!ms_out || reps < 1 || blocks < 1 || kind < 0 || kind > 17) return fail(MGCMT_ERR_INVALID, "bad arguments");
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
@@ -1101,7 +1101,7 @@ int mgcmt_bandwidth_probe(mgcmt_plan* p, int l, int kind, int blocks, int reps, 
       // (kind - 3) % 3: one read stream / two read streams / two reads + one write; (kind - 3) / 3: columns a wave
       // writes out of the 128 it reads: 128 (no overlap), 124 (unaligned), 112 (the fused kernels' geometry), 96
       launch_probe_march(S(stream), p->levels[l].nr, p->levels[l].gc, blocks, (kind - 3) % 3 == 0 ? 1 : 2, (kind - 3) % 3 == 2 ? 1 : 0,
-                         (kind - 3) / 3 == 0 ? 128 : ((kind - 3) / 3 == 1 ? 124 : ((kind - 3) / 3 == 2 ? 112 : 96)), p->kvec(l, MGCMT_SLOT_V).p,
+                         (kind - 3) / 3 == 0 ? 128 : ((kind - 3) / 3 == 1 ? 124 : ((kind - 3) / 3 == 2 ? 112 : ((kind - 3) / 3 == 3 ? 96 : 120))), p->kvec(l, MGCMT_SLOT_V).p,
                          p->kvec(l, MGCMT_SLOT_F).p, p->kvec(l, MGCMT_SLOT_T).p);
   };
   go();

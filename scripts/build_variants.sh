@@ -2,4 +2,4 @@ set -e
 cd "$(dirname "$0")/../multigridcmt_amd/csrc"
 rm -rf ../../build/variants ../../variants; mkdir -p ../../build/variants ../../variants
 build() { name=$1; shift; make -s -j8 OUT=$PWD/../../variants/lib_$name.so OBJDIR=$PWD/../../build/variants/obj_$name "$@"; echo built $name; }
-build dpp EXTRA=-DMGCMT_FUSED_DPP=1
+build wide_nostore EXTRA=-DMGCMT_FUSED_NARROW_NOSTORE=0

@@ -13,7 +13,8 @@ for rows in (328, 656):
     for kind, name, bpp in ((3, "march_read1", 8), (4, "march_read2", 16), (5, "march_triad", 24),
                             (6, "ovl_read1", 8), (7, "ovl_read2", 16), (8, "ovl_triad", 24),
                             (9, "w112_read1", 8), (10, "w112_read2", 16), (11, "w112_triad", 24),
-                            (12, "w96_read1", 8), (13, "w96_read2", 16), (14, "w96_triad", 24)):
+                            (12, "w96_read1", 8), (13, "w96_read2", 16), (14, "w96_triad", 24),
+                            (15, "w120_read1", 8), (16, "w120_read2", 16), (17, "w120_triad", 24)):
         ms = p.bandwidth_probe(0, kind, rows, 10)
         row[name + "_TBs"] = round(g * g * bpp / (ms * 1e-3) / 1e12, 3)
     print(json.dumps(row), flush=True)
