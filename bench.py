@@ -106,7 +106,7 @@ def main():
     value = n * sweeps * args.steps / elapsed / 1e6
     # dominant kernel: the fine-level smoother sweep, timed alone with HIP events on the same stream
     # (one launch = one fused pass of up to 2 sweeps: algorithmic bytes per launch = 24 B x points x sweeps in it)
-    reps = 10
+    reps = 25                      # >= 50 fine-level sweeps at the default nu
     fuse = plan.fused_max_sweeps(0, kind)
     launches = -(-args.nu // fuse) if fuse else args.nu * (1 if kind == _lib.WJACOBI else 4)
     ms = plan.time_smoother(0, kind, args.nu, omega, reps)
@@ -145,6 +145,18 @@ def main():
         "device": _lib.device_name(0),
     }
     out["roofline"]["traffic"] = measured_traffic(args)
+    # untimed: what the cycles being timed do to the residual: ||f - A v|| / ||f|| after each of
+    # ten cycles from a zero start
+    plan.fill(0, _lib.SLOT_V, 0, 0.0)
+    V, F, T = (_lib.SLOT_V, 0), (_lib.SLOT_F, 0), (_lib.SLOT_T, 0)
+    f_norm = np.sqrt(plan.dot(0, F, F))
+    history = []
+    for _ in range(10):
+        cycle()
+        plan.apply(0, V, T, with_shift=True)
+        plan.axpy(0, -1.0, F, T)
+        history.append(float(np.sqrt(plan.dot(0, T, T)) / f_norm))
+    out["residual_reduction_per_cycle"] = history
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.smoother)
     print(json.dumps(out))

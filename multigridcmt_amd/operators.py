@@ -182,8 +182,8 @@ def recognise(A, dimension=None):
     """StructuredOperator for a scipy.sparse matrix of the shapes the reference's callers build.
 
     1-D: any tridiagonal matrix.  2-D: a 5-point operator  I (x) Y + X (x) I  whose diagonal is
-    separable, d(i,j) = a(i) + b(j) — scaled / shifted Laplacians and separable potentials.  Anything
-    else raises UnrecognisedOperator: the HIP path has no general-sparse kernels and there is no CPU
+    d(i,j) = a(i) + b(j) [+ p(i) q(j)] — scaled / shifted Laplacians, separable potentials, and one product
+    potential on top (a square well).  Anything else raises UnrecognisedOperator: the HIP path has no general-sparse kernels and there is no CPU
     fallback.
     """
     if isinstance(A, StructuredOperator):
@@ -229,21 +229,34 @@ def recognise(A, dimension=None):
         ok = counted == nnz and not e[:, -1].any() and not w[:, 0].any()
         ok = ok and np.array_equal(e, np.broadcast_to(e[0], (g, g))) and np.array_equal(w, np.broadcast_to(w[0], (g, g)))
         ok = ok and np.array_equal(s, np.broadcast_to(s[:, :1], (g, g))) and np.array_equal(nn, np.broadcast_to(nn[:, :1], (g, g)))
+        extra = None
         if ok:
             c = 0.5 * d0[0, 0]
             yd = d0[0, :] - c
             xd = d0[:, 0] - d0[0, 0] + c
             scale = max(np.abs(d0).max(), 1e-300)
-            ok = np.abs(xd[:, None] + yd[None, :] - d0).max() <= 4 * np.finfo(float).eps * scale
+            rest = d0 - (xd[:, None] + yd[None, :])          # what an additively separable diagonal leaves over
+            if np.abs(rest).max() > 4 * np.finfo(float).eps * scale:
+                # a product potential on top, e.g. the square well V0 (1 - chi (x) chi) of PotWellSolver.py:150-153 in
+                # 2-D: the remainder must be ONE outer product p (x) q (the kernels take three Kronecker terms)
+                i0, j0 = np.unravel_index(np.argmax(np.abs(rest)), rest.shape)
+                p_, q_ = rest[:, j0] / rest[i0, j0], rest[i0, :].copy()
+                ok = np.abs(np.outer(p_, q_) - rest).max() <= 64 * np.finfo(float).eps * scale
+                extra = (p_, q_)
         if not ok:
             raise UnrecognisedOperator(
-                "2-D operator is not of the form I (x) Y + X (x) I with a separable diagonal; the HIP path "
-                "handles scaled/shifted Laplacians and separable potentials only")
+                "2-D operator is not of the form I (x) Y + X (x) I (+ one product potential p (x) q on the diagonal); "
+                "the HIP path handles scaled/shifted Laplacians with separable or square-well potentials only")
         Y = np.zeros((3, g))
         Y[0], Y[1], Y[2] = w[0], yd, e[0]
         X = np.zeros((3, g))
         X[0], X[1], X[2] = nn[:, 0], xd, s[:, 0]
-        op = StructuredOperator("2d", g, [(tri_identity(g), Y), (X, tri_identity(g))])
+        terms = [(tri_identity(g), Y), (X, tri_identity(g))]
+        if extra is not None:
+            dp, dq = np.zeros((3, g)), np.zeros((3, g))
+            dp[1], dq[1] = extra
+            terms.append((dp, dq))
+        op = StructuredOperator("2d", g, terms)
     if op is None:
         raise UnrecognisedOperator("operator is not tridiagonal (1-D)")
     if len(_CACHE) > 64:

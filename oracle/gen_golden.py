@@ -35,7 +35,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     devnull = open(os.devnull, "w")
 
+    only = set(sys.argv[1:])               # optional: names of the fixtures to (re)write; default all
+
     def save(name, **kw):
+        if only and name not in only:
+            return
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **kw)
         print("wrote", name, {k: np.shape(v) for k, v in kw.items()}, file=sys.stderr)
 
@@ -272,6 +276,25 @@ def main():
             hist[it, j] = V[:, j] @ (H @ V[:, j])
     save("driver_2dpot_matrix_vcycle", bad_vals=bad_vals, bad_vecs=bad_vecs, V0=V0, V_final=V,
          rq_history=hist, residual_history=res)
+    # ---- BASELINE config 5 at a size the reference can run: square-well Hamiltonian on a 2-D grid -------------------
+    # H = -laplacian/pi^2 + diag(V), V = depth outside the square [lo,hi)^2 (the potential of PotWellSolver.py:150-153
+    # carried to two dimensions), through the reference's own vcycle (2-D transfers) and rqmin (RQMin.py:18-27)
+    pw = {}
+    g, depth, lo, hi = 32, 30.0, 8, 24
+    chi = np.zeros(g)
+    chi[lo:hi] = 1.0
+    V = depth * (1.0 - np.outer(chi, chi)).reshape(-1)
+    Hw = ((-1 / np.pi ** 2) * sm.laplacian(g, dimension="2d") + sp.diags(V)).tocsr()
+    rng = np.random.RandomState(11)
+    f, x0 = rng.rand(g * g), rng.rand(g * g)
+    pw["g"], pw["depth"], pw["inner"], pw["f"], pw["x0"] = np.array(g), np.array(depth), np.array([lo, hi]), f, x0
+    for name, smo in (("wj", solver.wjacobi), ("gs", solver.gseidel)):
+        pw["vcycle_%s_v22_shift0.7_low8" % name] = _c(solver.vcycle(
+            _c(x0).reshape(-1, 1), _c(f).reshape(-1, 1), Hw, sm, nu1=2, nu2=2, shift=0.7, smoother=smo, dimension="2d",
+            lowest_level=8)).ravel()
+    x, rho = solver.rqmin(Hw, _c(x0), sp.eye(g * g), nu=6)
+    pw["rqmin_x"], pw["rqmin_rho"] = np.real(x), np.real(rho)
+    save("potential_well_2d", **pw)
     devnull.close()
 
 

@@ -209,3 +209,19 @@ def test_driver_reenactments():
             rq = np.array([V[:, j] @ (A @ V[:, j]) for j in range(k)])
             # Rayleigh quotients: 1e-10 relative (north_star); shifts sit next to eigenvalues
             assert np.allclose(rq, gold["rq_history"][it], rtol=1e-10, atol=0), (name, it)
+
+
+def test_oracle_square_well_hamiltonian():
+    """The sparse oracle on the reference's outputs for the 2-D square-well Hamiltonian (config 5)."""
+    gold = load_golden("potential_well_2d")
+    g, depth, (lo, hi) = int(gold["g"]), float(gold["depth"]), gold["inner"]
+    S, SM = RefSolver(), RefStencilMaker()
+    chi = np.zeros(g)
+    chi[lo:hi] = 1.0
+    H = ((-1 / np.pi ** 2) * SM.laplacian(g, dimension="2d") + sp.diags(depth * (1.0 - np.outer(chi, chi)).reshape(-1))).tocsr()
+    for name, smo in (("wj", S.wjacobi), ("gs", S.gseidel)):
+        w = S.vcycle(gold["x0"], gold["f"], H, SM, nu1=2, nu2=2, smoother=smo, shift=0.7, lowest_level=8, dimension="2d")
+        assert rel_err(w, gold["vcycle_%s_v22_shift0.7_low8" % name]) < 1e-11, name
+    x, rho = S.rqmin(H, gold["x0"], sp.eye(g * g), nu=6)
+    assert abs(np.real(rho) - float(gold["rqmin_rho"])) < 1e-11 * abs(float(gold["rqmin_rho"]))
+    assert rel_err(np.real(x), gold["rqmin_x"]) < 1e-9

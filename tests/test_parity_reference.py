@@ -317,3 +317,26 @@ def test_rayleigh_quotient_multigrid_two_dimensional(trio):
     import scipy.sparse.linalg as sla
     lowest = sla.eigsh(A, k=1, which="SA")[0][0]
     assert lowest <= rho < lowest * 1.05
+
+
+def test_square_well_hamiltonian_against_reference(trio):
+    """BASELINE config 5 at a size the reference runs (tests/golden/potential_well_2d.npz, written by running the
+    reference's own vcycle / rqmin on the assembled sparse Hamiltonian): the same sparse matrix handed to the product
+    is recognised as three Kronecker terms (Op9<3> kernels on every level) and must give the reference's numbers."""
+    solver, sm, _ = trio
+    gold = load_golden("potential_well_2d")
+    g, depth, (lo, hi) = int(gold["g"]), float(gold["depth"]), gold["inner"]
+    chi = np.zeros(g)
+    chi[lo:hi] = 1.0
+    H = ((-1 / np.pi ** 2) * sm.laplacian(g, dimension="2d") + sp.diags(depth * (1.0 - np.outer(chi, chi)).reshape(-1))).tocsr()
+    from multigridcmt_amd.operators import potential_well_operator, recognise
+    assert len(recognise(H).terms) == 3
+    assert abs(recognise(H).tocsr() - H).max() < 1e-12
+    assert abs(potential_well_operator(g, depth, (lo, hi)).tocsr() - H).max() < 1e-12
+    for name, smo in (("wj", solver.wjacobi), ("gs", solver.gseidel)):
+        w = solver.vcycle(gold["x0"].copy(), gold["f"].copy(), H, sm, nu1=2, nu2=2, shift=0.7, smoother=smo, dimension="2d",
+                          lowest_level=8)
+        assert rel_err(w, gold["vcycle_%s_v22_shift0.7_low8" % name]) < NORTH_STAR, name
+    x, rho = solver.rqmin(H, gold["x0"].copy(), sp.eye(g * g), nu=6)
+    assert abs(rho - float(gold["rqmin_rho"])) < NORTH_STAR * abs(float(gold["rqmin_rho"]))
+    assert rel_err(x, gold["rqmin_x"]) < 1e-8
