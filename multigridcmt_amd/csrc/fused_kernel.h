@@ -144,6 +144,7 @@ __device__ __forceinline__ double lane_shift(double v) {
 // constant 5-point operator: c0 on the diagonal, cn for the row neighbours, cw for the column ones
 struct Op5 {
   static constexpr bool kNine = false;
+  static constexpr bool kBigBody = false;
   double d, invd, cn, cw;
   __device__ __forceinline__ void init(const FusedArgs& a, int q, long, long) {
     d = a.c0 - a.shifts[q];
@@ -174,6 +175,7 @@ struct Op5 {
 // patched by a wave-uniform branch (fix_special).
 struct Op9c {
   static constexpr bool kNine = true;
+  static constexpr bool kBigBody = false;
   static constexpr bool kSpecialRow = true;
   double cnw, cn_, cne, cw_, ce_, csw, cs_, cse;  // interior (uniform)
   double vnb, vsb;                                  // north / south coefficients of column ja+1 (per lane)
@@ -241,6 +243,7 @@ __device__ __forceinline__ double fast_reciprocal(double d) {
 template <int M>
 struct Op9 {
   static constexpr bool kNine = true;
+  static constexpr bool kBigBody = true;  // its 12-step loop bodies are too long to exist twice (checked + steady state)
   static constexpr bool kSpecialRow = false;
   static constexpr int kRowValues = 3 * M;
   double mu;
@@ -287,6 +290,48 @@ struct Op9 {
     dg = dd - mu;
     inv = fast_reciprocal(dg);
   }
+};
+
+// constant 5-point operator plus MD product potentials p_m(i) q_m(j) on the diagonal (a square well on a scaled
+// Laplacian, PotWellSolver.py:150-153 carried to 2-D): the off-diagonal part is Op5's three scalars, the lane keeps
+// q_m of its two columns, p_m of a row travels through the LDS ring like Op9's row factors.
+template <int MD>
+struct Op5V {
+  static constexpr bool kNine = false;
+  static constexpr bool kBigBody = false;
+  static constexpr bool kSpecialRow = false;
+  static constexpr int kRowValues = MD;
+  double d0, cn, cw;
+  double qa[MD], qb[MD], p[MD];
+  __device__ __forceinline__ void init(const FusedArgs& a, int q, long ja, long nc) {
+    d0 = a.c0 - a.shifts[q];
+    cn = a.cn;
+    cw = a.cw;
+    const long j = ja < 0 ? 0 : (ja > nc - 2 ? nc - 2 : ja);
+#pragma unroll
+    for (int m = 0; m < MD; ++m) {
+      qa[m] = a.Y[m][j];
+      qb[m] = a.Y[m][j + 1];
+      p[m] = 0.0;
+    }
+  }
+  __device__ __forceinline__ double fetch_row(const FusedArgs& a, long rl, int lane) const { return a.X[lane < MD ? lane : MD - 1][rl]; }
+  __device__ __forceinline__ void set_row(const FusedArgs&, int, const double* ring_row) {
+#pragma unroll
+    for (int m = 0; m < MD; ++m) p[m] = ring_row[m];
+  }
+  __device__ __forceinline__ bool special_row(int) const { return false; }
+  template <int COL>
+  __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
+    off = fma(cn, n[1] + s[1], cw * (c[0] + c[2]));
+    double d = d0;
+#pragma unroll
+    for (int m = 0; m < MD; ++m) d = fma(p[m], COL == 0 ? qa[m] : qb[m], d);
+    dg = d;
+    inv = fast_reciprocal(d);
+  }
+  template <int COL>
+  __device__ __forceinline__ void fix_special(const double*, double&, double&, double&) const {}
 };
 
 enum { kJacobi = 0, kRedBlack = 1, kFourColour = 2 };
@@ -805,7 +850,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   // in a loop of their own (an `if` inside one loop would make the two bodies meet at the loop latch, where the
   // compiler then copies the whole register state and drains the prefetch); the checked body serves the few
   // iterations before and after, the outer two-trip loop only exists so that its code is emitted once.
-  constexpr bool kFastBody = OP::kRowValues == 0 || B == 6;  // (the general operator's 12-step bodies are too long to have twice)
+  constexpr bool kFastBody = !OP::kBigBody || B == 6;
   const int fast_lo = r_begin + S + XL + 3;
   const int fast_hi = (r_end + S + XL < row_hi ? r_end + S + XL : row_hi) - (B - 1);
   int base = rstart;
@@ -916,5 +961,6 @@ void launch_fused_op5(hipStream_t s, const fused::FusedArgs& a, int multicolour,
 void launch_fused_op9c(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);
 void launch_fused_op9(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);    // two terms
 void launch_fused_op9m3(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);  // three terms
+void launch_fused_op5v(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);   // 5-point + product potential
 
 }  // namespace mgcmt

@@ -26,18 +26,18 @@ constexpr long kFusedMinCols = MGCMT_FUSED_MIN_COLS;
 // separable operators of two or three Kronecker terms (Laplacian plus potential).  Narrow levels run too (one partly filled wave per
 // chunk): a fused pass there replaces four to nine tiny launches, which is what small levels cost.
 bool fused_supported(const KGrid& g, const KOp& op) {
-  return g.coarsen_rows && g.nr >= 4 && g.nc >= kFusedMinCols && (g.nc & 1) == 0 && (g.nr & 1) == 0 && (op.five_point || op.nine_const || op.nterms == 2 || op.nterms == 3);
+  return g.coarsen_rows && g.nr >= 4 && g.nc >= kFusedMinCols && (g.nc & 1) == 0 && (g.nr & 1) == 0 && (op.five_point || op.five_diag || op.nine_const || op.nterms == 2 || op.nterms == 3);
 }
 
 // sweeps one pass can fuse.  A 9-point four-colour sweep is four stages: two of them plus the restriction read nine
 // rows above the chunk, one more than a strip's MGCMT_HALO_ROWS, so strips (sharded levels) fuse one.
-int fused_max_sweeps(const KOp& op, int multicolour, bool strip) { return (!op.five_point && multicolour && strip) ? 1 : 2; }
+int fused_max_sweeps(const KOp& op, int multicolour, bool strip) { return (!op.five_point && !op.five_diag && multicolour && strip) ? 1 : 2; }
 
 // sweeps of pre-smoothing an up-leg pass with `nsweep` post-smoothing sweeps can recompute in front of the
 // correction (0: none): all stages plus the correction must fit the window overlap (16 columns at most) and
 // the eight halo rows of a strip
 int fused_max_recompute(const KOp& op, int multicolour, int nsweep) {
-  if (!op.five_point && multicolour) return 0;                  // four-colour sweeps: four stages each
+  if (!op.five_point && !op.five_diag && multicolour) return 0;  // four-colour sweeps: four stages each
   const int per_sweep = multicolour ? 2 : 1;
   int n = (8 - per_sweep * nsweep) / per_sweep;
   return n < 0 ? 0 : (n > 2 ? 2 : n);
@@ -75,6 +75,12 @@ void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, K
   const int flags = (mode & 15) | (npre << fused::kPreShift);
   if (op.five_point) {
     launch_fused_op5(s, a, multicolour, nsweep, flags, k);
+  } else if (op.five_diag) {
+    for (int m = 0; m < op.ndiag; ++m) {
+      a.X[m] = op.dX[m];
+      a.Y[m] = op.dY[m];
+    }
+    launch_fused_op5v(s, a, multicolour, nsweep, flags, k);
   } else if (op.nine_const) {
     for (int i = 0; i < 3; ++i) {
       for (int j = 0; j < 3; ++j) a.c9[i][j] = op.c9[i][j];

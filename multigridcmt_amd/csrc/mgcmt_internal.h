@@ -29,6 +29,11 @@ struct KOp {
   // coefficients on the last column, and the corner's diagonal
   int nine_const;
   double c9[3][3], c9row[3], c9col[3], c9corner;
+  // five_diag: a constant 5-point part (c0/cn/cw) plus ndiag (1 or 2) terms whose factors are both diagonal — a
+  // product potential p(i) q(j) on top of a scaled Laplacian (square well): dX[m][row], dY[m][col] are the diagonals
+  int five_diag, ndiag;
+  const double* dX[2];
+  const double* dY[2];
 };
 
 // A batch of vectors on one level: interior pointer of vector 0, elements between vectors.

@@ -220,8 +220,42 @@ int upload_op(const HostOp& h, const Level& L, int dim, DevOp* d) {
     k.cn = c[0][1];
     k.cw = c[1][0];
   }
+  // constant 5-point part plus ONE product potential on the diagonal: the Toeplitz terms form a 5-point operator,
+  // the remaining term has diagonal factors only
+  if (!k.five_point && dim == 2 && h.nterms >= 2) {
+    auto diagonal_only = [](const Tri& t) {
+      for (int64_t i = 0; i < t.n; ++i)
+        if ((i > 0 && t.lo(i) != 0.0) || (i + 1 < t.n && t.up(i) != 0.0)) return false;
+      return true;
+    };
+    double c5[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    int nd = 0, dm[2] = {0, 0};
+    bool ok = true;
+    for (int m = 0; m < h.nterms && ok; ++m) {
+      double x[3], y[3];
+      if (toeplitz(h.X[m], &x[0], &x[1], &x[2]) && toeplitz(h.Y[m], &y[0], &y[1], &y[2])) {
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) c5[a][b] += x[a] * y[b];
+      } else if (diagonal_only(h.X[m]) && diagonal_only(h.Y[m]) && nd < 1) {
+        dm[nd++] = m;
+      } else {
+        ok = false;
+      }
+    }
+    if (ok && nd == 1 && c5[0][0] == 0 && c5[0][2] == 0 && c5[2][0] == 0 && c5[2][2] == 0 && c5[0][1] == c5[2][1] && c5[1][0] == c5[1][2]) {
+      k.five_diag = 1;
+      k.ndiag = nd;
+      k.c0 = c5[1][1];
+      k.cn = c5[0][1];
+      k.cw = c5[1][0];
+      for (int t = 0; t < nd; ++t) {
+        k.dX[t] = k.X[dm[t]] + k.ldx;  // the diagonal row of the factor arrays ([lower | diag | upper])
+        k.dY[t] = k.Y[dm[t]] + k.ldy;
+      }
+    }
+  }
   // Galerkin levels of a constant operator: Toeplitz factors whose last diagonal entry differs
-  if (!k.five_point && dim == 2 && h.nterms > 0) {
+  if (!k.five_point && !k.five_diag && dim == 2 && h.nterms > 0) {
     auto toeplitz_but_last = [](const Tri& t, double* lo, double* di, double* up, double* last) {
       if (t.n < 3) return false;
       *di = t.di(0);

@@ -92,7 +92,7 @@ def rayleigh_quotient_multigrid(gridsize=2 ** 6, first_cycles=2, second_cycles=1
 
 
 def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8, method="vcycle", nu=2, lowest=8,
-                              smoother="rb", seed=0, history=None):
+                              smoother="rb", seed=0, history=None, stats=None):
     """BASELINE config 5: the ground state of the 2-D square well  H = -laplacian/pi^2 + V  (V = `depth` outside the
     central square, PotWellSolver.py:150-153 carried to 2-D) by Rayleigh-quotient minimisation on the GPU.
 
@@ -102,7 +102,8 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
                      quotient over span{x, w} — the 2x2 problem of rqmin (MGCMTSolver.py:44-50) with the
                      preconditioned residual as the search direction.  All vector work stays in HBM; the host sees six
                      inner products per iteration.
-    Returns (rho, x); ``history`` (a list) receives rho after every cycle."""
+    Returns (rho, x); ``history`` (a list) receives rho after every cycle, ``stats`` (a dict) the seconds spent in
+    the iteration loop alone (start vector generation and the host transfers excluded)."""
     from . import _lib
     from .operators import identity_operator, potential_well_operator
     from .plan import get_plan
@@ -131,6 +132,8 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
     plan.scale(0, 1.0 / np.sqrt(plan.dot(0, X, X)), X)
     plan.apply(0, X, AX)
     rho = plan.dot(0, X, AX)
+    import time
+    loop_start = time.perf_counter()
     for _ in range(cycles):
         plan.copy(0, AX[0], AX[1], F, 0)                 # r = H x - rho x
         plan.axpy(0, -rho, X, (F, 0))
@@ -150,4 +153,6 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
         rho = plan.dot(0, X, AX)
         if history is not None:
             history.append(rho)
+    if stats is not None:
+        stats["loop_seconds"] = time.perf_counter() - loop_start
     return rho, plan.download(0, W, 0)

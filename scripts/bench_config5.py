@@ -39,7 +39,10 @@ for method, cycles in (("vcycle", 10), ("rqmg", 3)):
     hist = []
     drivers.potential_well_eigensolve(g, cycles=1, method=method)          # plan creation, graph capture
     t = time.perf_counter()
-    rho, _ = drivers.potential_well_eigensolve(g, cycles=cycles, method=method, history=hist)
+    stats = {}
+    rho, _ = drivers.potential_well_eigensolve(g, cycles=cycles, method=method, history=hist, stats=stats)
     out["%s_seconds_%d_cycles" % (method, cycles)] = time.perf_counter() - t
+    if "loop_seconds" in stats:
+        out["%s_ms_per_iteration" % method] = stats["loop_seconds"] / cycles * 1e3
     out["%s_rho" % method] = hist
 print(json.dumps(out, indent=1))

@@ -190,6 +190,11 @@ def test_potential_well_operator_three_terms(backend):
     rng = np.random.RandomState(17)
     v0, f = rng.rand(g * g), rng.rand(g * g)
     S, SM = RefSolver(), RefStencilMaker()
+    # the finest level is a 5-point operator with a product potential (two-colour Gauss-Seidel, recompute allowed),
+    # its Galerkin coarsenings are general three-term 9-point operators (four colours)
+    p = Plan(op, 8, nvec=1)
+    assert p.fused_max_recompute(0, _lib.GS_MC, 2) == 2 and p.fused_max_recompute(1, _lib.GS_MC, 2) == 0
+    p.close()
     for kind, omega, smo in ((_lib.WJACOBI, 2. / 3., S.wjacobi),
                              (_lib.GS_MC, 1.0, lambda v, f, A, nu=4: S.gseidel_mc(v, f, A, nu=nu, dimension="2d"))):
         outs = []
