@@ -12,12 +12,13 @@ from oracle import structured as st
 SCALE = -1 / np.pi ** 2
 
 
-def _run(g, fused, kind, omega, what, nu, shift=0.7, k=1, gs=False, seed=0, rows=0):
+def _run(g, fused, kind, omega, what, nu, shift=0.7, k=1, gs=False, seed=0, rows=0, recompute=1):
     op = laplacian_operator(g, "2d") * SCALE
     rng = np.random.RandomState(seed)
     p = Plan(op, 8, nvec=k)
     p.set_option(_lib.OPT_FUSED, fused)
     p.set_option(_lib.OPT_FUSED_ROWS, rows)      # rows a wave marches over (0 = automatic); process-wide
+    p.set_option(_lib.OPT_RECOMPUTE, recompute)  # 2: recompute-instead-of-store on every fused level
     p.set_shifts(np.full(k, shift) + 0.1 * np.arange(k))
     for q in range(k):
         p.upload(0, _lib.SLOT_V, q, rng.rand(g * g))
@@ -51,9 +52,10 @@ def test_fused_chunk_lengths(backend, kind, omega):
     ref, cref = _run(256, 0, kind, omega, "vcycle", 2)
     try:
         for rows in (6, 22, 64, 256):
-            a, ca = _run(256, 1, kind, omega, "vcycle", 2, rows=rows)
-            assert rel_err(a, ref) < 1e-12, rows
-            assert rel_err(ca, cref) < 1e-12, rows
+            for recompute in (1, 2):
+                a, ca = _run(256, 1, kind, omega, "vcycle", 2, rows=rows, recompute=recompute)
+                assert rel_err(a, ref) < 1e-12, (rows, recompute)
+                assert rel_err(ca, cref) < 1e-12, (rows, recompute)
     finally:
         _run(16, 1, kind, omega, "smooth", 1, rows=0)     # back to automatic
 
