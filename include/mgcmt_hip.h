@@ -134,6 +134,14 @@ int mgcmt_prolong(mgcmt_plan* plan, int level, int src_slot, int src_vec, int ds
 /* vector algebra (MGCMTProcessor.py:10-73; np.dot / np.linalg.norm call sites of MGCMTSolver.py) */
 int mgcmt_dot(mgcmt_plan* plan, int level, int slot_a, int vec_a, int slot_b, int vec_b, double* host_out, void* stream);
 int mgcmt_axpy(mgcmt_plan* plan, int level, double alpha, int x_slot, int x_vec, int y_slot, int y_vec, void* stream);
+/* all inner products <v_a, v_b> of nv <= 6 vectors (slots[a], vecs[a]) in ONE pass over the data; host_out is the
+ * symmetric nv x nv Gram matrix, row-major.  The Rayleigh-Ritz steps of rqmin (MGCMTSolver.py:44-50: the entries of
+ * its 2x2 matrices R and RM) and of the eigen-drivers need such sets; synchronises like mgcmt_dot. */
+int mgcmt_gram(mgcmt_plan* plan, int level, int nv, const int* slots, const int* vecs, double* host_out, void* stream);
+/* dst = sum_t coeffs[t] * (slots[t], vecs[t]), 1 <= nterms <= 4; dst may be one of the inputs (the updates
+ * x <- x + delta p, MGCMTSolver.py:52, and the residual A x - rho M x, :22-23, in one pass each) */
+int mgcmt_lincomb(mgcmt_plan* plan, int level, int nterms, const double* coeffs, const int* slots, const int* vecs, int dst_slot,
+                  int dst_vec, void* stream);
 int mgcmt_scale(mgcmt_plan* plan, int level, double alpha, int slot, int vec, void* stream);
 /* in-place Gram-Schmidt of vectors 0..k-1 of `slot`: modified != 0 -> MGS (:44-50), else CGS (:34-42) */
 int mgcmt_gramschmidt(mgcmt_plan* plan, int level, int slot, int k, int modified, void* stream);

@@ -213,6 +213,62 @@ __global__ void __launch_bounds__(kMgsSmallThreads) k_mgs_small(long n, double* 
   }
 }
 
+// Gram matrix of up to kGramMax vectors in one pass (each vector is read once): partial sums of <v_a, v_b>, a <= b,
+// in the order (0,0),(0,1),...,(0,nv-1),(1,1),...  — the 2x2 Rayleigh-Ritz problems of rqmin (MGCMTSolver.py:44-50)
+// and of the eigen-drivers need exactly such a set.  Deterministic (fixed per-thread order, fixed tree).
+constexpr int kGramMax = 6;
+struct GramArgs {
+  const double* v[kGramMax];
+};
+__global__ void __launch_bounds__(kRedThreads) k_gram_partial(long n, GramArgs g, int nv, double* __restrict__ partials) {
+  constexpr int kWaves = kRedThreads / 64;
+  constexpr int kPairs = kGramMax * (kGramMax + 1) / 2;
+  __shared__ double s_part[kWaves][kPairs];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc[kPairs];
+#pragma unroll
+  for (int t = 0; t < kPairs; ++t) acc[t] = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double x[kGramMax];
+#pragma unroll
+    for (int a = 0; a < kGramMax; ++a) x[a] = a < nv ? g.v[a][i] : 0.0;
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < kGramMax; ++a)
+#pragma unroll
+      for (int b = a; b < kGramMax; ++b) {
+        if (b < nv) acc[t] = fma(x[a], x[b], acc[t]);  // (slots of pairs beyond nv stay zero and are skipped by the host)
+        ++t;
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < kPairs; ++t) {
+    const double tot = wave_sum(acc[t]);
+    if (lane == 0) s_part[wave][t] = tot;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < kPairs) {
+    double tot = 0.0;
+    for (int w = 0; w < kWaves; ++w) tot += s_part[w][threadIdx.x];
+    partials[(long)threadIdx.x * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
+// dst = sum_t c[t] v_t  (dst may be one of the inputs: every element is read before it is written)
+struct LincombArgs {
+  const double* v[4];
+  double c[4];
+};
+__global__ void k_lincomb(long n, LincombArgs a, int nt, double* dst) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double acc = a.c[0] * a.v[0][i];
+#pragma unroll
+    for (int t = 1; t < 4; ++t)
+      if (t < nt) acc = fma(a.c[t], a.v[t][i], acc);
+    dst[i] = acc;
+  }
+}
+
 // bandwidth probes (bench.py's empirical HBM ceilings): 16-byte accesses, grid-stride
 __global__ void k_probe_copy(long n2, const double2* __restrict__ a, double2* __restrict__ out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) out[i] = a[i];
@@ -322,6 +378,24 @@ void launch_scale_by_norm(hipStream_t s, long n, const double* partials, double*
 
 void launch_project_out(hipStream_t s, long n, const double* partials, const double* q, double* a_first, long astride, int nj) {
   hipLaunchKernelGGL(k_project_out, dim3(blocks_for(n), nj), dim3(256), 0, s, n, partials, reduce_blocks(n), q, a_first, astride);
+}
+
+// out[t] (device) = <v_a, v_b> for the pairs a <= b < nv in the packed order of k_gram_partial over kGramMax vectors
+void launch_gram(hipStream_t s, long n, const double* const* v, int nv, double* partials, double* out) {
+  GramArgs g{};
+  for (int a = 0; a < kGramMax; ++a) g.v[a] = v[a < nv ? a : 0];
+  const int nb = reduce_blocks(n);
+  hipLaunchKernelGGL(k_gram_partial, dim3(nb), dim3(kRedThreads), 0, s, n, g, nv, partials);
+  hipLaunchKernelGGL(k_dot_final, dim3(kGramMax * (kGramMax + 1) / 2), dim3(kRedThreads), 0, s, nb, partials, out);
+}
+
+void launch_lincomb(hipStream_t s, long n, const double* const* v, const double* c, int nt, double* dst) {
+  LincombArgs a{};
+  for (int t = 0; t < 4; ++t) {
+    a.v[t] = v[t < nt ? t : 0];
+    a.c[t] = t < nt ? c[t] : 0.0;
+  }
+  hipLaunchKernelGGL(k_lincomb, dim3(blocks_for(n)), dim3(256), 0, s, n, a, nt, dst);
 }
 
 bool mgs_small_fits(long n) { return n <= kMgsSmallMaxN; }

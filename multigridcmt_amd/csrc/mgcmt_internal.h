@@ -93,6 +93,9 @@ void launch_dots(hipStream_t s, long n, const double* x, const double* y, long y
 void launch_dot_partials(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials);
 void launch_scale_by_norm(hipStream_t s, long n, const double* partials, double* x);
 void launch_project_out(hipStream_t s, long n, const double* partials, const double* q, double* a_first, long astride, int nj);
+constexpr int kGramMaxVectors = 6;
+void launch_gram(hipStream_t s, long n, const double* const* v, int nv, double* partials, double* out);
+void launch_lincomb(hipStream_t s, long n, const double* const* v, const double* c, int nt, double* dst);
 bool mgs_small_fits(long n);
 void launch_mgs_small(hipStream_t s, long n, double* a0, long stride, int k);
 void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out);

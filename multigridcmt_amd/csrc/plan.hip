@@ -1008,6 +1008,44 @@ int mgcmt_dot(mgcmt_plan* p, int l, int slot_a, int vec_a, int slot_b, int vec_b
   return MGCMT_OK;
 }
 
+int mgcmt_gram(mgcmt_plan* p, int l, int nv, const int* slots, const int* vecs, double* host_out, void* stream) {
+  MG_TRY(check_level(p, l));
+  if (!slots || !vecs || !host_out || nv < 1 || nv > kGramMaxVectors) return fail(MGCMT_ERR_INVALID, "gram: 1..6 vectors, non-null arguments");
+  const double* v[kGramMaxVectors];
+  for (int a = 0; a < nv; ++a) {
+    MG_TRY(check_vec(p, l, slots[a], vecs[a]));
+    MG_TRY(ensure_slot(p, l, slots[a]));
+    v[a] = p->kvec(l, slots[a], vecs[a]).p;
+  }
+  constexpr int kPairs = kGramMaxVectors * (kGramMaxVectors + 1) / 2;
+  launch_gram(S(stream), p->interior(l), v, nv, p->d_partials, p->d_scalars);
+  MG_TRY(post_launch());
+  double packed[kPairs];
+  MG_HIP(hipMemcpyAsync(packed, p->d_scalars, sizeof(packed), hipMemcpyDeviceToHost, S(stream)));
+  MG_HIP(hipStreamSynchronize(S(stream)));
+  int t = 0;
+  for (int a = 0; a < kGramMaxVectors; ++a)
+    for (int b = a; b < kGramMaxVectors; ++b, ++t)
+      if (b < nv) host_out[a * nv + b] = host_out[b * nv + a] = packed[t];
+  return MGCMT_OK;
+}
+
+int mgcmt_lincomb(mgcmt_plan* p, int l, int nterms, const double* coeffs, const int* slots, const int* vecs, int dst_slot, int dst_vec,
+                  void* stream) {
+  MG_TRY(check_level(p, l));
+  if (!coeffs || !slots || !vecs || nterms < 1 || nterms > 4) return fail(MGCMT_ERR_INVALID, "lincomb: 1..4 terms, non-null arguments");
+  MG_TRY(check_vec(p, l, dst_slot, dst_vec));
+  MG_TRY(ensure_slot(p, l, dst_slot));
+  const double* v[4];
+  for (int t = 0; t < nterms; ++t) {
+    MG_TRY(check_vec(p, l, slots[t], vecs[t]));
+    MG_TRY(ensure_slot(p, l, slots[t]));
+    v[t] = p->kvec(l, slots[t], vecs[t]).p;
+  }
+  launch_lincomb(S(stream), p->interior(l), v, coeffs, nterms, p->kvec(l, dst_slot, dst_vec).p);
+  return post_launch();
+}
+
 int mgcmt_axpy(mgcmt_plan* p, int l, double alpha, int x_slot, int x_vec, int y_slot, int y_vec, void* stream) {
   MG_TRY(check_vec(p, l, x_slot, x_vec));
   MG_TRY(check_vec(p, l, y_slot, y_vec));

@@ -100,8 +100,9 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
     method="vcycle"  Rayleigh-quotient minimisation with a V-cycle preconditioner: every iteration applies one V(nu,nu)
                      cycle of H (from a zero start) to the eigen-residual r = H x - rho x and minimises the Rayleigh
                      quotient over span{x, w} — the 2x2 problem of rqmin (MGCMTSolver.py:44-50) with the
-                     preconditioned residual as the search direction.  All vector work stays in HBM; the host sees six
-                     inner products per iteration.
+                     preconditioned residual as the search direction.  All vector work stays in HBM: per iteration
+                     three fused linear combinations, one operator application and ONE Gram-matrix pass whose ten
+                     numbers are all the host sees.
     Returns (rho, x); ``history`` (a list) receives rho after every cycle, ``stats`` (a dict) the seconds spent in
     the iteration loop alone (start vector generation and the host transfers excluded)."""
     from . import _lib
@@ -135,22 +136,19 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
     import time
     loop_start = time.perf_counter()
     for _ in range(cycles):
-        plan.copy(0, AX[0], AX[1], F, 0)                 # r = H x - rho x
-        plan.axpy(0, -rho, X, (F, 0))
+        plan.lincomb(0, [(1.0, AX), (-rho, X)], (F, 0))                               # r = H x - rho x
         plan.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu, zero_start=True)        # w = B r
         plan.apply(0, PW, AW)
-        xx, xw, ww = plan.dot(0, X, X), plan.dot(0, X, PW), plan.dot(0, PW, PW)
-        xax, xaw, waw = plan.dot(0, X, AX), plan.dot(0, X, AW), plan.dot(0, PW, AW)
+        G = plan.gram(0, [X, PW, AX, AW])                                             # one pass, one host round trip
+        xx, xw, ww = G[0, 0], G[0, 1], G[1, 1]
+        xax, xaw, waw = G[0, 2], 0.5 * (G[0, 3] + G[1, 2]), G[1, 3]
         evals, evecs = scipy.linalg.eigh(np.array([[xax, xaw], [xaw, waw]]), np.array([[xx, xw], [xw, ww]]))
         a, b = evecs[:, 0]
-        plan.scale(0, a, X)
-        plan.axpy(0, b, PW, X)
-        plan.scale(0, a, AX)
-        plan.axpy(0, b, AW, AX)
-        nrm = np.sqrt(plan.dot(0, X, X))
-        plan.scale(0, 1.0 / nrm, X)
-        plan.scale(0, 1.0 / nrm, AX)
-        rho = plan.dot(0, X, AX)
+        nrm = np.sqrt(a * a * xx + 2 * a * b * xw + b * b * ww)                       # |a x + b w|
+        a, b = a / nrm, b / nrm
+        plan.lincomb(0, [(a, X), (b, PW)], X)
+        plan.lincomb(0, [(a, AX), (b, AW)], AX)
+        rho = float(evals[0])                                                         # = <x, H x> of the new x
         if history is not None:
             history.append(rho)
     if stats is not None:

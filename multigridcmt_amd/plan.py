@@ -151,6 +151,23 @@ class Plan:
         check(_lib.lib().mgcmt_dot(self._h, level, a[0], a[1], b[0], b[1], ctypes.byref(out), stream))
         return out.value
 
+    def gram(self, level, vectors, stream=None):
+        """Gram matrix (len(vectors) <= 6) of the (slot, vec) pairs in one pass; synchronises."""
+        nv = len(vectors)
+        slots = (ctypes.c_int * nv)(*[v[0] for v in vectors])
+        vecs = (ctypes.c_int * nv)(*[v[1] for v in vectors])
+        out = np.zeros((nv, nv))
+        check(_lib.lib().mgcmt_gram(self._h, level, nv, slots, vecs, _lib.as_dp(out), stream))
+        return out
+
+    def lincomb(self, level, terms, dst, stream=None):
+        """dst <- sum of coeff * (slot, vec) over `terms` = [(coeff, (slot, vec)), ...] (at most four)."""
+        nt = len(terms)
+        coeffs = np.array([float(c) for c, _ in terms])
+        slots = (ctypes.c_int * nt)(*[v[0] for _, v in terms])
+        vecs = (ctypes.c_int * nt)(*[v[1] for _, v in terms])
+        check(_lib.lib().mgcmt_lincomb(self._h, level, nt, _lib.as_dp(coeffs), slots, vecs, dst[0], dst[1], stream))
+
     def axpy(self, level, alpha, x, y, stream=None):
         check(_lib.lib().mgcmt_axpy(self._h, level, c_double(alpha), x[0], x[1], y[0], y[1], stream))
 

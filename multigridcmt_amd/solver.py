@@ -257,48 +257,46 @@ class MGCMTSolver:
     _RQ_REGS = 10
 
     def _rqmin_device(self, plan, level, nu):
-        """rqmin (MGCMTSolver.py:17-57) on the registers of `level`; x is register _X.  The vector
-        work (8 operator applications, ~12 inner products, 3 axpys per step) runs on the GPU; the
-        2x2 generalised eigenproblem on span{x, p} (:48-50) is solved on the host."""
+        """rqmin (MGCMTSolver.py:17-57) on the registers of `level`; x is register _X.  The vector work (6 operator
+        applications and a handful of fused passes per step) runs on the GPU: every group of inner products the
+        reference takes one by one (:19-21, :34-35, :44-47) is ONE Gram-matrix pass with one host round trip
+        (mgcmt_gram), every update one fused linear combination; the 2x2 generalised eigenproblem on span{x, p}
+        (:48-50) is solved on the host."""
         V = SLOT_V
         X, P, G, GOLD, AX, AP, MX, MP, TMP, TMP2 = [(V, r) for r in range(10)]
-        dot = lambda a, b: plan.dot(level, a, b)
 
-        def apply_both():
+        def rayleigh():                          # A x, M x and rho = <x,Ax>/<x,Mx>
             plan.apply(level, X, AX, op=OP_A)
             plan.apply(level, X, MX, op=OP_M)
+            g = plan.gram(level, [X, AX, MX])
+            return g[0, 1] / g[0, 2]
 
         def gradient(rho):                       # g = 2 (A x - rho M x)
-            plan.copy(level, AX[0], AX[1], G[0], G[1])
-            plan.axpy(level, -rho, MX, G)
-            plan.scale(level, 2.0, G)
+            plan.lincomb(level, [(2.0, AX), (-2.0 * rho, MX)], G)
 
-        apply_both()
-        rho = dot(X, AX) / dot(X, MX)
+        rho = rayleigh()
         plan.copy(level, X[0], X[1], GOLD[0], GOLD[1])
         gradient(rho)
         plan.copy(level, X[0], X[1], P[0], P[1])
         for it in range(nu):
             if it == 0:
-                plan.copy(level, G[0], G[1], P[0], P[1])
-                plan.scale(level, -1.0, P)
+                plan.lincomb(level, [(-1.0, G)], P)
             else:
                 plan.apply(level, G, TMP, op=OP_M)
                 plan.apply(level, GOLD, TMP2, op=OP_M)
-                beta = dot(G, TMP) / dot(GOLD, TMP2)
-                plan.scale(level, beta, P)
-                plan.axpy(level, -1.0, G, P)
-            apply_both()
-            plan.apply(level, P, AP, op=OP_A)
+                gg = plan.gram(level, [G, TMP, GOLD, TMP2])
+                beta = gg[0, 1] / gg[2, 3]
+                plan.lincomb(level, [(beta, P), (-1.0, G)], P)
+            plan.apply(level, P, AP, op=OP_A)                  # (A x, M x are those of the last rayleigh())
             plan.apply(level, P, MP, op=OP_M)
-            R = np.array([[dot(X, AX), dot(X, AP)], [dot(P, AX), dot(P, AP)]])
-            RM = np.array([[dot(X, MX), dot(X, MP)], [dot(P, MX), dot(P, MP)]])
+            gm = plan.gram(level, [X, P, AX, AP, MX, MP])
+            R = np.array([[gm[0, 2], gm[0, 3]], [gm[1, 2], gm[1, 3]]])
+            RM = np.array([[gm[0, 4], gm[0, 5]], [gm[1, 4], gm[1, 5]]])
             w, vecs = scipy.linalg.eig(R, b=RM)
             y = vecs[:, np.argmin(w)]
             delta = float(np.real(y[1] / y[0]))
             plan.axpy(level, delta, P, X)
-            apply_both()
-            rho = dot(X, AX) / dot(X, MX)
+            rho = rayleigh()
             plan.copy(level, G[0], G[1], GOLD[0], GOLD[1])
             gradient(rho)
         return rho

@@ -111,3 +111,28 @@ def test_one_dimensional_variable_coefficients(trio):
         x = solver.vcycle(np.zeros(n), f.copy(), A, sm, nu1=2, nu2=2, smoother=smo, shift=1.1, lowest_level=4)
         y = S.vcycle(np.zeros(n), f, A, SM, nu1=2, nu2=2, smoother=rsmo, shift=1.1, lowest_level=4)
         assert rel_err(x, y) < 1e-10
+
+
+def test_gram_matrix_and_linear_combinations(backend):
+    """mgcmt_gram / mgcmt_lincomb (the fused vector algebra of the Rayleigh-Ritz steps) against NumPy, 1-D and 2-D,
+    including a destination that is one of the inputs."""
+    from multigridcmt_amd import _lib
+    from multigridcmt_amd.operators import laplacian_operator
+    from multigridcmt_amd.plan import Plan
+    rng = np.random.RandomState(4)
+    for op in (laplacian_operator(1024, "1d"), laplacian_operator(64, "2d")):
+        p = Plan(op, 8, nvec=3)
+        n = p.size(0)
+        vs = rng.rand(6, n) - 0.5
+        where = [(_lib.SLOT_V, 0), (_lib.SLOT_V, 1), (_lib.SLOT_F, 2), (_lib.SLOT_W, 0), (_lib.SLOT_W, 1), (_lib.SLOT_F, 0)]
+        for v, (slot, q) in zip(vs, where):
+            p.upload(0, slot, q, v)
+        for nv in (1, 2, 4, 6):
+            G = p.gram(0, where[:nv])
+            assert np.allclose(G, vs[:nv] @ vs[:nv].T, rtol=1e-12, atol=1e-12)
+            assert np.array_equal(G, G.T)
+        p.lincomb(0, [(0.5, where[0]), (-2.0, where[1]), (3.0, where[2]), (0.25, where[3])], where[4])
+        assert rel_err(p.download(0, *where[4]), 0.5 * vs[0] - 2.0 * vs[1] + 3.0 * vs[2] + 0.25 * vs[3]) < 1e-14
+        p.lincomb(0, [(1.5, where[0]), (-1.0, where[5])], where[0])          # in place
+        assert rel_err(p.download(0, *where[0]), 1.5 * vs[0] - vs[5]) < 1e-14
+        p.close()
