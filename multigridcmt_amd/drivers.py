@@ -69,6 +69,69 @@ def shift_invert_eigenpairs(dimension="1d", gridsize=2 ** 7, bad_gridsize=2 ** 4
             "history": history}
 
 
+def shift_invert_eigenpairs_resident(dimension="2d", gridsize=2 ** 10, bad_gridsize=2 ** 4, num_eigenvalues=10, max_iters=5,
+                                     lowest_level=None, tolerance=1e-4, guesses=None, smoother=None, stats=None):
+    """The same outer loop as ``shift_invert_eigenpairs`` (1DPotMatrixVcycle.py:42-80 / 2DPotMatrixVcycle.py:54-109)
+    with everything between the coarse-grid Lanczos guesses and the final download resident on the GPU: the guesses
+    are interpolated level by level inside the plan, every iteration is one k-column V-cycle with Gram-Schmidt
+    (the reference's vcycle_matrix), a column normalisation, k device copies and k Rayleigh quotients (one operator
+    application and one two-vector Gram pass each).  For grids whose k columns are too large to shuttle over PCIe
+    every iteration (or to assemble as a sparse matrix at all).  Returns the same dict; ``stats`` receives the seconds
+    spent in the iteration loop."""
+    import time
+    from . import _lib
+    from .operators import laplacian_operator
+    from .plan import Plan
+    stencil_maker, solver = MGCMTStencilMaker(), MGCMTSolver()
+    g, k = int(gridsize), int(num_eigenvalues)
+    if lowest_level is None:
+        lowest_level = 2 ** 4 if dimension == "1d" else 2 ** 3
+    lowest_level = min(int(lowest_level), int(bad_gridsize))
+    if guesses is None:
+        bad_hamiltonian = (-1. / np.pi ** 2) * stencil_maker.laplacian(bad_gridsize, dimension=dimension)
+        bad_eigenvalues, bad_eigenvectors = sparsela.eigsh(bad_hamiltonian, k=k, which="SM", tol=tolerance)
+    else:
+        bad_eigenvalues, bad_eigenvectors = guesses
+    bad_eigenvalues, bad_eigenvectors = np.asarray(bad_eigenvalues, dtype=float), np.array(bad_eigenvectors, dtype=float)
+    kind, omega = solver._resolve_smoother(smoother)
+    V, F, W = _lib.SLOT_V, _lib.SLOT_F, _lib.SLOT_W
+    plan = Plan(laplacian_operator(g, dimension) * (-1 / np.pi ** 2), lowest_level, nvec=k)
+    try:
+        lb = (g // int(bad_gridsize)).bit_length() - 1          # level of the guess grid
+        for j in range(k):
+            plan.upload(lb, F, j, bad_eigenvectors[:, j])
+            for l in range(lb - 1, -1, -1):
+                plan.prolong(l, (F, j), (F, j), accumulate=False)
+        plan.normalize(0, F, k)
+        plan.set_shifts(np.zeros(k))
+
+        def rayleigh_quotients(slot):
+            out = np.zeros(k)
+            for j in range(k):
+                plan.apply(0, (slot, j), (W, j))
+                out[j] = plan.gram(0, [(slot, j), (W, j)])[0, 1]
+            return out
+
+        history = np.zeros((max_iters + 1, k))
+        history[0] = rayleigh_quotients(F)
+        plan.sync()
+        start = time.perf_counter()
+        for it in range(1, max_iters + 1):
+            plan.set_shifts(bad_eigenvalues)
+            plan.vcycle(4, 4, kind, omega=omega, k=k, nu_coarse=4, gram_schmidt=True, zero_start=True)
+            plan.normalize(0, V, k)
+            for j in range(k):
+                plan.copy(0, V, j, F, j)
+            history[it] = rayleigh_quotients(F)
+        plan.sync()
+        if stats is not None:
+            stats["loop_seconds"] = time.perf_counter() - start
+        vectors = np.stack([plan.download(0, F, j) for j in range(k)], axis=1)
+    finally:
+        plan.close()
+    return {"eigenvalues": history[-1].copy(), "eigenvectors": vectors, "guess_eigenvalues": bad_eigenvalues, "history": history}
+
+
 def rayleigh_quotient_multigrid(gridsize=2 ** 6, first_cycles=2, second_cycles=10, seed=0):
     """RQMin.py:15-50 for the two lowest states of -laplacian(gridsize)/pi^2 with M = I: ``first_cycles`` sweeps of
     vcycle_rqmg on a random start, then ``second_cycles`` sweeps on a second random vector with Gram-Schmidt against

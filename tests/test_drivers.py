@@ -5,7 +5,7 @@ report (AndyMartinez_MultigridExamen.pdf p.21-22 and p.44, quoted in BASELINE.md
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, rel_err
 from multigridcmt_amd import drivers
 
 
@@ -69,3 +69,22 @@ def test_potential_well_eigensolve_two_dimensional(backend):
     assert np.linalg.norm(H @ x - rho * x) < 1e-5 * np.linalg.norm(x)
     rho_mg, _ = drivers.potential_well_eigensolve(g, depth=50.0, cycles=4, method="rqmg", nu=4, lowest=4)
     assert lowest <= rho_mg < lowest * (1 + 1e-3)
+
+
+@pytest.mark.parametrize("dimension,g,bad,fixture,iters,lowest", [("1d", 128, 16, "driver_1dpot_matrix_vcycle", 10, 16),
+                                                                  ("2d", 32, 8, "driver_2dpot_matrix_vcycle", 3, 4)])
+def test_resident_driver_equals_host_driver(backend, dimension, g, bad, fixture, iters, lowest):
+    """The device-resident outer loop (guesses interpolated inside the plan, k-column cycles, normalisation and
+    Rayleigh quotients without shuttling the columns over PCIe) computes what the host-array loop computes — which for
+    these fixtures is what the reference's 1DPotMatrixVcycle.py / 2DPotMatrixVcycle.py compute."""
+    gold = load_golden(fixture)
+    k = gold["bad_vecs"].shape[1]
+    guesses = (gold["bad_vals"], gold["bad_vecs"])
+    stats = {}
+    res = drivers.shift_invert_eigenpairs_resident(dimension, g, bad, k, iters, lowest_level=lowest, guesses=guesses, stats=stats)
+    host = drivers.shift_invert_eigenpairs(dimension, g, bad, k, iters, lowest_level=lowest, guesses=guesses)
+    assert np.allclose(res["history"], host["history"], rtol=1e-10, atol=0)
+    assert np.allclose(res["history"][1:], gold["rq_history"], rtol=1e-10, atol=0)
+    for j in range(k):
+        assert rel_err(res["eigenvectors"][:, j], host["eigenvectors"][:, j]) < 1e-9
+    assert stats["loop_seconds"] > 0
