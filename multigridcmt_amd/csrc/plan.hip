@@ -1133,7 +1133,8 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
     return MGCMT_OK;
   }
   if (option == MGCMT_OPT_FUSED_ROWS) {
-    fused_set_rows(value);
+    fused_set_rows(value);  // process-wide tuning knob: captured graphs of OTHER plans keep their launch geometry
+    p->graphs_invalidate();
     return MGCMT_OK;
   }
   return fail(MGCMT_ERR_INVALID, "unknown option");
