@@ -159,6 +159,35 @@ class MGCMTSolver:
             return v.reshape(n, 1)
         return v
 
+    def fmg(self, f, A, stencil_maker, nu1=4, nu2=4, smoother=None, shift=0, lowest_level=2, dimension="1d", *,
+            nu_coarse=4, cycles_per_level=1):
+        """Full multigrid / nested iteration (an ADDITION: the reference's report describes it as the next step — PDF
+        p.17 "FMG", p.51 — but its code has no such function).  The right-hand side is restricted through all levels
+        (full weighting, the R of MGCMTStencilMaker.py:57-78), the coarsest problem is solved directly, and on the way
+        up every level takes the interpolated coarser solution as its start value and runs ``cycles_per_level``
+        V-cycles (the ones of ``vcycle``: V(nu1,nu2) on their top level, V(nu_coarse,nu_coarse) below) on the
+        Galerkin operator of that level.  Returns the fine-grid solution; about 4/3 (2-D) of the work of one V-cycle
+        per cycle and level.  Built from the same C-ABI calls as ``vcycle``."""
+        kind, omega = self._resolve_smoother(smoother)
+        n = len(f)
+        g = self._grid(n, dimension)
+        if not self._check_grid(g, lowest_level):
+            return None
+        op = recognise(A, dimension)
+        plan = get_plan(op, int(lowest_level), nvec=1)
+        plan.set_shifts([float(shift)])
+        V, F = (SLOT_V, 0), (SLOT_F, 0)
+        plan.upload(0, SLOT_F, 0, np.asarray(f, dtype=np.float64).reshape(-1))
+        last = plan.num_levels - 1
+        for l in range(last):
+            plan.restrict(l, F, F)                                  # f_{l+1} = R f_l
+        plan.coarse_solve(last)
+        for l in range(last - 1, -1, -1):
+            plan.prolong(l, V, V, accumulate=False)                 # start value: P v_{l+1}
+            for _ in range(int(cycles_per_level)):
+                plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=1, nu_coarse=int(nu_coarse), level=l)
+        return plan.download(0, SLOT_V, 0)
+
     def twogrid(self, v0, f, A, stencil_maker, nu1=4, nu2=4, smoother=None, shift=0, dimension="1d"):
         """MGCMTSolver.py:331-371 — pre-smooth, exact solve of (R A P - shift I) on the next grid,
         post-smooth.  (The reference sizes the coarse shift as n/2 (:350) and therefore only runs in

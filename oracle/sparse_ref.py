@@ -319,6 +319,32 @@ class RefSolver:
             g = 2 * (A @ x - rho * (M @ x))
         return x, rho
 
+    def fmg(self, f, A, stencil_maker, nu1=4, nu2=4, smoother=None, shift=0, lowest_level=2, dimension="1d",
+            cycles_per_level=1):
+        """Full multigrid built from the reference's own pieces (NOT a reference function — PARITY UNPINNED; it is the
+        oracle of MGCMTSolver.fmg, an addition): restrict f through the levels with `restriction`, solve on
+        `lowest_level` as vcycle does (MGCMTSolver.py:305-308), then per level interpolate and run `vcycle` on the
+        Galerkin operator of that level (:318)."""
+        f = _col(f)
+        g = len(f) if dimension == "1d" else int(round(math.sqrt(len(f))))
+        ops, rhs, grids = [sp.csr_matrix(A)], [f], [g]
+        while grids[-1] > lowest_level:
+            gl = grids[-1]
+            R = stencil_maker.restriction(gl, gl // 2, dimension=dimension)
+            P = stencil_maker.interpolation(gl // 2, gl, dimension=dimension)
+            ops.append(sp.csr_matrix(R @ ops[-1] @ P))
+            rhs.append(R @ rhs[-1])
+            grids.append(gl // 2)
+        nl = ops[-1].shape[0]
+        v = spsolve((ops[-1] - shift * sp.eye(nl)).tocsc(), rhs[-1]).reshape(-1)
+        for l in range(len(ops) - 2, -1, -1):
+            P = stencil_maker.interpolation(grids[l + 1], grids[l], dimension=dimension)
+            v = P @ v
+            for _ in range(cycles_per_level):
+                v = self.vcycle(v, rhs[l], ops[l], stencil_maker, nu1=nu1, nu2=nu2, smoother=smoother, shift=shift,
+                                lowest_level=lowest_level, dimension=dimension).reshape(-1)
+        return v
+
     def vcycle_rqmg(self, x, A, M, nu1=4, nu2=4, nmin=2, dimension="1d"):
         """MGCMTSolver.py:99-122 — restricts the iterate itself, Galerkin A_c and M_c (:110-111).
         dimension="2d" (not in the reference, whose transfers here are 1-D only, :107-108) runs the same algorithm

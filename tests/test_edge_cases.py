@@ -136,3 +136,24 @@ def test_gram_matrix_and_linear_combinations(backend):
         p.lincomb(0, [(1.5, where[0]), (-1.0, where[5])], where[0])          # in place
         assert rel_err(p.download(0, *where[0]), 1.5 * vs[0] - vs[5]) < 1e-14
         p.close()
+
+
+@pytest.mark.parametrize("dimension,g,lowest", [("1d", 256, 4), ("2d", 64, 8)])
+def test_full_multigrid(trio, dimension, g, lowest):
+    """MGCMTSolver.fmg (an addition; the reference only describes FMG in its report): equal to the oracle's FMG built
+    from the reference-equivalent pieces, and one FMG pass leaves a far smaller residual than one V-cycle from zero."""
+    from oracle.sparse_ref import RefSolver, RefStencilMaker
+    solver, sm, _ = trio
+    A = (-1 / np.pi ** 2) * sm.laplacian(g, dimension=dimension)
+    n = A.shape[0]
+    f = np.random.RandomState(8).rand(n)
+    S, SM = RefSolver(), RefStencilMaker()
+    Asp = (-1 / np.pi ** 2) * SM.laplacian(g, dimension=dimension)
+    for smo, rsmo in ((solver.wjacobi, S.wjacobi), (solver.gseidel, S.gseidel)):
+        w = solver.fmg(f.copy(), A, sm, nu1=2, nu2=2, smoother=smo, shift=0.3, lowest_level=lowest, dimension=dimension)
+        ref = S.fmg(f, Asp, SM, nu1=2, nu2=2, smoother=rsmo, shift=0.3, lowest_level=lowest, dimension=dimension)
+        assert rel_err(w, ref) < 1e-10
+    shifted = Asp - 0.3 * sp.eye(n)
+    one_cycle = solver.vcycle(np.zeros(n), f.copy(), A, sm, nu1=2, nu2=2, shift=0.3, lowest_level=lowest, dimension=dimension)
+    w = solver.fmg(f.copy(), A, sm, nu1=2, nu2=2, shift=0.3, lowest_level=lowest, dimension=dimension)
+    assert np.linalg.norm(f - shifted @ w) < 0.5 * np.linalg.norm(f - shifted @ one_cycle)     # (a rough random f)
