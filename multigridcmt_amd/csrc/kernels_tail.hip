@@ -1,0 +1,226 @@
+// The tail of a V-cycle in ONE launch: every level of at most 64 x 64 points, from the first such level down to the
+// coarsest grid and back up (MGCMTSolver.py:310-326 for those levels, the direct solve of :305-308 as a product
+// with the explicit inverse), held in LDS by one 1024-thread workgroup per vector.  On these levels a launch costs
+// more than its work: the fused passes, the coarse solve and their launch gaps (7 to 11 launches, 60-90 us) become
+// about 10 us.  The arithmetic is that of the one-launch-per-operation kernels (kernels_stencil.hip): the general
+// separable operator sum_m X_m (x) Y_m from the level's factor arrays, weighted Jacobi or four-colour Gauss-Seidel.
+#include "mgcmt_internal.h"
+
+namespace mgcmt {
+
+namespace {
+
+constexpr int kTailThreads = 1024;
+constexpr int kTailMaxGrid = 64;
+// 2 x sum g_l^2 (V, F) + g_0^2 (scratch) + factors: 2*5461 + 4096 + 4 terms * 6 * 127 < 18100 doubles (141 KiB)
+constexpr int kTailLds = 18100;
+
+struct Layout {
+  int g0, nlev, nterms;
+  __device__ __forceinline__ int g(int l) const { return g0 >> l; }
+  __device__ __forceinline__ int s2(int l) const {  // sum of g_i^2, i < l
+    int t = 0;
+    for (int i = 0; i < l; ++i) t += (g0 >> i) * (g0 >> i);
+    return t;
+  }
+  __device__ __forceinline__ int s1(int l) const {  // sum of g_i, i < l
+    int t = 0;
+    for (int i = 0; i < l; ++i) t += g0 >> i;
+    return t;
+  }
+  __device__ __forceinline__ int v(int l) const { return s2(l); }
+  __device__ __forceinline__ int f(int l) const { return s2(nlev) + s2(l); }
+  __device__ __forceinline__ int t() const { return 2 * s2(nlev); }
+  // factor `which` (0 = X, 1 = Y) of term m on level l: three parts (lower, diag, upper) of g_l numbers each
+  __device__ __forceinline__ int fac(int l, int m, int which) const { return 2 * s2(nlev) + g0 * g0 + s1(l) * nterms * 6 + (m * 2 + which) * 3 * g(l); }
+};
+
+struct Point {
+  double off, diag;
+};
+
+// neighbour sum and diagonal at (i, j) of a g x g level held in LDS (zero Dirichlet ghosts), as eval_point of
+// kernels_stencil.hip
+__device__ __forceinline__ Point tail_point(const double* sm, const Layout& L, int l, const double* v, int i, int j) {
+  const int g = L.g(l);
+  const bool hn = i > 0, hs = i + 1 < g, hw = j > 0, he = j + 1 < g;
+  const double* c = v + i * g + j;
+  const double n = hn ? c[-g] : 0.0, s = hs ? c[g] : 0.0, w = hw ? c[-1] : 0.0, e = he ? c[1] : 0.0;
+  const double nw = hn && hw ? c[-g - 1] : 0.0, ne = hn && he ? c[-g + 1] : 0.0;
+  const double sw = hs && hw ? c[g - 1] : 0.0, se = hs && he ? c[g + 1] : 0.0;
+  Point r{0.0, 0.0};
+  for (int m = 0; m < L.nterms; ++m) {
+    const double* X = sm + L.fac(l, m, 0) + i;
+    const double* Y = sm + L.fac(l, m, 1) + j;
+    const double xl = X[0], xd = X[g], xu = X[2 * g];
+    const double yl = Y[0], yd = Y[g], yu = Y[2 * g];
+    const double rn = yl * nw + yd * n + yu * ne;
+    const double rc = yl * w + yu * e;
+    const double rs = yl * sw + yd * s + yu * se;
+    r.off += xl * rn + xd * rc + xu * rs;
+    r.diag += xd * yd;
+  }
+  return r;
+}
+
+// nu sweeps on level l (V in LDS, in place for the caller): weighted Jacobi through the scratch array, or four-colour
+// Gauss-Seidel in the order (0,1),(1,0),(0,0),(1,1) of kernels_stencil.hip
+__device__ void tail_smooth(double* sm, const Layout& L, int l, int kind, int nu, double omega, double mu) {
+  const int g = L.g(l), n = g * g;
+  double* V = sm + L.v(l);
+  const double* F = sm + L.f(l);
+  if (kind == MGCMT_WJACOBI) {
+    double* cur = V;
+    double* nxt = sm + L.t();
+    for (int it = 0; it < nu; ++it) {
+      for (int p = threadIdx.x; p < n; p += kTailThreads) {
+        const int i = p / g, j = p - i * g;
+        const Point pt = tail_point(sm, L, l, cur, i, j);
+        const double d = pt.diag - mu;
+        const double vc = cur[p];
+        nxt[p] = vc + omega * ((F[p] - (pt.off + d * vc)) / d);
+      }
+      __syncthreads();
+      double* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+    if (cur != V) {
+      for (int p = threadIdx.x; p < n; p += kTailThreads) V[p] = cur[p];
+      __syncthreads();
+    }
+    return;
+  }
+  const int h = g >> 1 > 0 ? g >> 1 : 1;
+  for (int it = 0; it < nu; ++it) {
+    for (int c = 0; c < 4; ++c) {
+      const int ca = (c == 1 || c == 3) ? 1 : 0, cb = (c == 0 || c == 3) ? 1 : 0;
+      for (int p = threadIdx.x; p < h * h; p += kTailThreads) {
+        const int i = 2 * (p / h) + ca, j = 2 * (p % h) + cb;
+        if (i < g && j < g) {
+          const Point pt = tail_point(sm, L, l, V, i, j);
+          const double d = pt.diag - mu;
+          const double vc = V[i * g + j];
+          V[i * g + j] = vc + omega * ((F[i * g + j] - (pt.off + d * vc)) / d);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kTailThreads) k_tail(TailArgs a) {
+  __shared__ double sm[kTailLds];
+  const int q = blockIdx.x;
+  const Layout L{a.g0, a.nlev, a.nterms};
+  const double mu = a.shifts[q];
+  // operator factors of every tail level
+  for (int l = 0; l < L.nlev; ++l) {
+    const int g = L.g(l);
+    for (int m = 0; m < L.nterms; ++m)
+      for (int x = threadIdx.x; x < 3 * g; x += kTailThreads) {
+        const int part = x / g, i = x - part * g;
+        sm[L.fac(l, m, 0) + x] = a.X[l][m][part * a.ldx[l] + i];
+        sm[L.fac(l, m, 1) + x] = a.Y[l][m][part * a.ldy[l] + i];
+      }
+  }
+  {  // entry level: right-hand side from memory, zero start value (the error equation, MGCMTSolver.py:316)
+    const int n = L.g0 * L.g0;
+    const double* f = a.f_in + q * a.vstride;
+    for (int p = threadIdx.x; p < n; p += kTailThreads) {
+      sm[L.f(0) + p] = f[p];
+      sm[L.v(0) + p] = 0.0;
+    }
+  }
+  __syncthreads();
+  for (int l = 0; l + 1 < L.nlev; ++l) {
+    const int g = L.g(l), gc = g >> 1;
+    tail_smooth(sm, L, l, a.kind, a.nu, a.omega, mu);
+    // residual into the scratch array, then full weighting (rows / columns 2I..2I+2, weights 1/4 1/2 1/4)
+    double* R = sm + L.t();
+    const double* V = sm + L.v(l);
+    const double* F = sm + L.f(l);
+    for (int p = threadIdx.x; p < g * g; p += kTailThreads) {
+      const int i = p / g, j = p - i * g;
+      const Point pt = tail_point(sm, L, l, V, i, j);
+      R[p] = F[p] - (pt.off + (pt.diag - mu) * V[p]);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < gc * gc; p += kTailThreads) {
+      const int I = p / gc, J = p - I * gc;
+      const int j0 = 2 * J;
+      const bool h2 = j0 + 2 < g;
+      double rows[3];
+      for (int r = 0; r < 3; ++r) {
+        const int i = 2 * I + r;
+        if (i < g) {
+          const double* x = R + i * g + j0;
+          rows[r] = 0.25 * x[0] + 0.5 * x[1] + (h2 ? 0.25 * x[2] : 0.0);
+        } else {
+          rows[r] = 0.0;
+        }
+      }
+      sm[L.f(l + 1) + p] = 0.25 * rows[0] + 0.5 * rows[1] + 0.25 * rows[2];
+      sm[L.v(l + 1) + p] = 0.0;
+    }
+    __syncthreads();
+  }
+  {  // coarsest grid: x = (A - mu I)^-1 f with the explicit inverse (row i contiguous)
+    const int l = L.nlev - 1, n = L.g(l) * L.g(l);
+    const double* inv = a.inv + q * a.inv_stride;
+    const double* F = sm + L.f(l);
+    for (int i = threadIdx.x; i < n; i += kTailThreads) {
+      const double* row = inv + (long)i * n;
+      double acc = 0.0;
+      for (int j = 0; j < n; ++j) acc += row[j] * F[j];
+      sm[L.v(l) + i] = acc;
+    }
+    __syncthreads();
+  }
+  for (int l = L.nlev - 2; l >= 0; --l) {
+    const int g = L.g(l), gc = g >> 1;
+    double* V = sm + L.v(l);
+    const double* C = sm + L.v(l + 1);
+    // V += P C: odd fine index takes c[(k-1)/2], even the mean of c[k/2-1] and c[k/2] (c[-1] = 0)
+    for (int p = threadIdx.x; p < g * g; p += kTailThreads) {
+      const int i = p / g, j = p - i * g;
+      const int I = i >> 1, J = j >> 1;
+      const bool jodd = j & 1;
+      const double* r1 = C + I * gc;
+      const double a1 = jodd ? r1[J] : 0.5 * (r1[J] + (J > 0 ? r1[J - 1] : 0.0));
+      double val = a1;
+      if (!(i & 1)) {
+        double a0 = 0.0;
+        if (I > 0) {
+          const double* r0 = r1 - gc;
+          a0 = jodd ? r0[J] : 0.5 * (r0[J] + (J > 0 ? r0[J - 1] : 0.0));
+        }
+        val = 0.5 * (a0 + a1);
+      }
+      V[p] += val;
+    }
+    __syncthreads();
+    tail_smooth(sm, L, l, a.kind, a.nu, a.omega, mu);
+  }
+  {
+    const int n = L.g0 * L.g0;
+    double* v = a.v_out + q * a.vstride;
+    for (int p = threadIdx.x; p < n; p += kTailThreads) v[p] = sm[L.v(0) + p];
+  }
+}
+
+}  // namespace
+
+bool tail_fits(long g0, int nlev, int nterms) {
+  if (g0 > kTailMaxGrid || nlev < 2 || nlev > kTailMaxLevels || nterms > kMaxTerms) return false;
+  long s2 = 0, s1 = 0;
+  for (int l = 0; l < nlev; ++l) {
+    s2 += (g0 >> l) * (g0 >> l);
+    s1 += g0 >> l;
+  }
+  return 2 * s2 + g0 * g0 + s1 * nterms * 6 <= kTailLds;
+}
+
+void launch_tail(hipStream_t s, const TailArgs& a, int k) { hipLaunchKernelGGL(k_tail, dim3((unsigned)k), dim3(kTailThreads), 0, s, a); }
+
+}  // namespace mgcmt

@@ -97,6 +97,25 @@ constexpr int kGramMaxVectors = 6;
 void launch_gram(hipStream_t s, long n, const double* const* v, int nv, double* partials, double* out);
 void launch_lincomb(hipStream_t s, long n, const double* const* v, const double* c, int nt, double* dst);
 bool mgs_small_fits(long n);
+
+// the levels of at most 64 x 64 points of a V-cycle in one launch (kernels_tail.hip)
+constexpr int kTailMaxLevels = 6;
+struct TailArgs {
+  int g0, nlev, nterms;       // entry grid (g0 x g0), number of levels, Kronecker terms per level
+  const double* X[kTailMaxLevels][kMaxTerms];
+  const double* Y[kTailMaxLevels][kMaxTerms];
+  long ldx[kTailMaxLevels], ldy[kTailMaxLevels];
+  const double* f_in;         // entry level right-hand side (vector 0), vstride between vectors
+  double* v_out;              // entry level result
+  long vstride;
+  const double* inv;          // explicit inverse of the coarsest (A - mu I), one n x n block per vector
+  long inv_stride;
+  const double* shifts;
+  double omega;
+  int kind, nu;               // smoother and sweeps (pre and post) on every tail level
+};
+bool tail_fits(long g0, int nlev, int nterms);
+void launch_tail(hipStream_t s, const TailArgs& a, int k);
 void launch_mgs_small(hipStream_t s, long n, double* a0, long stride, int k);
 void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out);
 

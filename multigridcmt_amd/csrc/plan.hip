@@ -132,6 +132,7 @@ struct mgcmt_plan {
   std::vector<double> h_shifts;
   bool has_mass = false;
   bool use_fused = true;
+  bool use_tail = true;   // levels of at most 64 x 64 points as one launch (kernels_tail.hip)
   bool use_recompute = true;  // down-leg passes skip storing V', up-leg passes recompute it (fused_kernel.h)
   bool force_recompute = false;  // ... on every fused level, not only the bandwidth-bound ones (tests)
   // HIP-graph replay of whole cycles (mgcmt_vcycle): the launch sequence of a cycle is fixed by its
@@ -436,7 +437,9 @@ int prolong_correct_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
   return post_launch();
 }
 
-int coarse_solve_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
+// the factorisation (and, for at most 1024 unknowns, the explicit inverse) of the coarsest-level matrix for the current
+// shifts: allocated on first use, redone when the shifts change
+int ensure_coarse_ready(mgcmt_plan* p, int l, int k, hipStream_t s) {
   Level& L = p->levels[l];
   if (L.nr != L.gr) return fail(MGCMT_ERR_UNSUPPORTED, "direct solve on a row strip");
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
@@ -466,6 +469,14 @@ int coarse_solve_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
     B.k = k;
     B.shifts.assign(p->h_shifts.begin(), p->h_shifts.begin() + k);
   }
+  return post_launch();
+}
+
+int coarse_solve_impl(mgcmt_plan* p, int l, int k, hipStream_t s) {
+  MG_TRY(ensure_coarse_ready(p, l, k, s));
+  Level& L = p->levels[l];
+  BandState& B = L.band;
+  const long n = (long)L.nr * L.gc;
   if (B.inv) launch_dense_solve(s, n, B.inv, n * n, p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_V), k);
   else launch_band_solve(s, B.b, p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_V), k);
   return post_launch();
@@ -601,20 +612,72 @@ int ensure_coarse_factor(mgcmt_plan* p, int l, int k, hipStream_t s) {
   return post_launch();
 }
 
+// First level of the cycle's tail: the levels of at most 64 x 64 points below the level the cycle starts on run as
+// ONE launch (kernels_tail.hip).  -1: no tail (1-D, strips, lexicographic smoothers, Gram-Schmidt between the levels,
+// a coarsest grid too large for the explicit inverse, or nothing to gain).
+int tail_level(const mgcmt_plan* p, int level, int kind, int nu_coarse, int gram_schmidt) {
+  const int last = (int)p->levels.size() - 1;
+  if (!p->use_tail || !p->use_fused || p->dim != 2 || gram_schmidt || nu_coarse < 1) return -1;
+  if (kind != MGCMT_WJACOBI && kind != MGCMT_GS_MC) return -1;
+  const Level& C = p->levels[last];
+  if (C.nr != C.gr || (long)C.nr * C.gc > 1024) return -1;
+  for (int l = level + 1; l < last; ++l) {
+    const Level& L = p->levels[l];
+    if (L.nr != L.gr || L.gr != L.gc) continue;
+    if (tail_fits(L.gr, last - l + 1, L.dA.k.nterms)) return l;
+  }
+  return -1;
+}
+
+int run_tail(mgcmt_plan* p, int lt, int kind, int nu, double omega, int k, hipStream_t s) {
+  const int last = (int)p->levels.size() - 1;
+  MG_TRY(ensure_coarse_ready(p, last, k, s));
+  MG_TRY(ensure_slot(p, lt, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, lt, MGCMT_SLOT_F));
+  TailArgs a{};
+  a.g0 = (int)p->levels[lt].gr;
+  a.nlev = last - lt + 1;
+  a.nterms = p->levels[lt].dA.k.nterms;
+  for (int l = lt; l <= last; ++l) {
+    const KOp& op = p->levels[l].dA.k;
+    for (int m = 0; m < op.nterms; ++m) {
+      a.X[l - lt][m] = op.X[m];
+      a.Y[l - lt][m] = op.Y[m];
+    }
+    a.ldx[l - lt] = op.ldx;
+    a.ldy[l - lt] = op.ldy;
+  }
+  a.f_in = p->kvec(lt, MGCMT_SLOT_F).p;
+  a.v_out = p->kvec(lt, MGCMT_SLOT_V).p;
+  a.vstride = p->kvec(lt, MGCMT_SLOT_V).stride;
+  const long n = (long)p->levels[last].nr * p->levels[last].gc;
+  a.inv = p->levels[last].band.inv;
+  a.inv_stride = n * n;
+  a.shifts = p->d_shifts;
+  a.omega = omega;
+  a.kind = kind;
+  a.nu = nu;
+  launch_tail(s, a, k);
+  return post_launch();
+}
+
 int vcycle_body(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k, int gram_schmidt,
                 hipStream_t s) {
   const int last = (int)p->levels.size() - 1;
+  const int lt = tail_level(p, level, kind, nu_coarse, gram_schmidt);
+  const int bottom = lt > 0 ? lt : last;  // the levels level .. bottom-1 run as fused passes / single launches
   std::vector<int> recompute(last + 1, 0);
   std::vector<char> still_zero(last + 1, 0);
-  for (int l = level; l < last; ++l) {
+  for (int l = level; l < bottom; ++l) {
     const int nu_up = l == level ? nu2 : nu_coarse;
     bool sz = false;
     // the up-leg can only recompute the unstored sweeps if it runs a fused pass itself (>= 1 post-smoothing sweep)
     MG_TRY(down_leg(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, l > level, s, nu_up >= 1 ? &recompute[l] : nullptr, &sz, nu_up));
     still_zero[l] = sz;
   }
-  MG_TRY(coarse_solve_impl(p, last, k, s));
-  for (int l = last - 1; l >= level; --l) {
+  if (lt > 0) MG_TRY(run_tail(p, lt, kind, nu_coarse, omega, k, s));
+  else MG_TRY(coarse_solve_impl(p, last, k, s));
+  for (int l = bottom - 1; l >= level; --l) {
     MG_TRY(up_leg(p, l, kind, l == level ? nu2 : nu_coarse, omega, k, s, recompute[l], still_zero[l] != 0));
     if (gram_schmidt) MG_TRY(gramschmidt_impl(p, l, MGCMT_SLOT_V, k, 1, s));
   }
@@ -1130,6 +1193,11 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
   }
   if (option == MGCMT_OPT_GRAPH) {
     p->use_graph = value != 0;
+    return MGCMT_OK;
+  }
+  if (option == MGCMT_OPT_TAIL) {
+    p->use_tail = value != 0;
+    p->graphs_invalidate();
     return MGCMT_OK;
   }
   if (option == MGCMT_OPT_FUSED_ROWS) {
