@@ -1,8 +1,9 @@
-// The tail of a V-cycle in ONE launch: every level of at most 64 x 64 points, from the first such level down to the
+// The tail of a V-cycle in ONE launch: every level of at most 32 x 32 points, from the first such level down to the
 // coarsest grid and back up (MGCMTSolver.py:310-326 for those levels, the direct solve of :305-308 as a product
 // with the explicit inverse), held in LDS by one 1024-thread workgroup per vector.  On these levels a launch costs
-// more than its work: the fused passes, the coarse solve and their launch gaps (7 to 11 launches, 60-90 us) become
-// about 10 us.  The arithmetic is that of the one-launch-per-operation kernels (kernels_stencil.hip): the general
+// more than its work: five launches (two fused passes per level and the coarse solve, ~43 us under graph replay)
+// become one of ~30 us, paced by its ~45 barrier-separated phases.  (Measured: starting the tail at 64 x 64 does not
+// pay — one CU's LDS bandwidth then costs what the launches did.)  The arithmetic is that of the one-launch-per-operation kernels (kernels_stencil.hip): the general
 // separable operator sum_m X_m (x) Y_m from the level's factor arrays, weighted Jacobi or four-colour Gauss-Seidel.
 #include "mgcmt_internal.h"
 
@@ -11,9 +12,9 @@ namespace mgcmt {
 namespace {
 
 constexpr int kTailThreads = 1024;
-constexpr int kTailMaxGrid = 64;
-// 2 x sum g_l^2 (V, F) + g_0^2 (scratch) + factors: 2*5461 + 4096 + 4 terms * 6 * 127 < 18100 doubles (141 KiB)
-constexpr int kTailLds = 18100;
+constexpr int kTailMaxGrid = 32;
+// 2 x sum g_l^2 (V, F) + g_0^2 (scratch) + factors: 2*1365 + 1024 + 4 terms * 6 * 63 < 5400 doubles (42 KiB)
+constexpr int kTailLds = 5400;
 
 struct Layout {
   int g0, nlev, nterms;
@@ -39,43 +40,71 @@ struct Point {
   double off, diag;
 };
 
+// one level as the point loops see it: everything that depends on the level only, computed once per phase
+struct View {
+  int g, nterms;
+  double* V;
+  const double* F;
+  const double* X[kMaxTerms];  // lower | diag | upper, g numbers each
+  const double* Y[kMaxTerms];
+};
+
+__device__ __forceinline__ View make_view(double* sm, const Layout& L, int l) {
+  View w;
+  w.g = L.g(l);
+  w.nterms = L.nterms;
+  w.V = sm + L.v(l);
+  w.F = sm + L.f(l);
+  const int base = L.fac(l, 0, 0);
+#pragma unroll
+  for (int m = 0; m < kMaxTerms; ++m) {
+    w.X[m] = sm + base + (m * 2 + 0) * 3 * w.g;
+    w.Y[m] = sm + base + (m * 2 + 1) * 3 * w.g;
+  }
+  return w;
+}
+
 // neighbour sum and diagonal at (i, j) of a g x g level held in LDS (zero Dirichlet ghosts), as eval_point of
 // kernels_stencil.hip
-__device__ __forceinline__ Point tail_point(const double* sm, const Layout& L, int l, const double* v, int i, int j) {
-  const int g = L.g(l);
+__device__ __forceinline__ Point tail_point(const View& w, const double* v, int i, int j) {
+  const int g = w.g;
   const bool hn = i > 0, hs = i + 1 < g, hw = j > 0, he = j + 1 < g;
   const double* c = v + i * g + j;
-  const double n = hn ? c[-g] : 0.0, s = hs ? c[g] : 0.0, w = hw ? c[-1] : 0.0, e = he ? c[1] : 0.0;
+  const double n = hn ? c[-g] : 0.0, s = hs ? c[g] : 0.0, wv = hw ? c[-1] : 0.0, e = he ? c[1] : 0.0;
   const double nw = hn && hw ? c[-g - 1] : 0.0, ne = hn && he ? c[-g + 1] : 0.0;
   const double sw = hs && hw ? c[g - 1] : 0.0, se = hs && he ? c[g + 1] : 0.0;
   Point r{0.0, 0.0};
-  for (int m = 0; m < L.nterms; ++m) {
-    const double* X = sm + L.fac(l, m, 0) + i;
-    const double* Y = sm + L.fac(l, m, 1) + j;
-    const double xl = X[0], xd = X[g], xu = X[2 * g];
-    const double yl = Y[0], yd = Y[g], yu = Y[2 * g];
-    const double rn = yl * nw + yd * n + yu * ne;
-    const double rc = yl * w + yu * e;
-    const double rs = yl * sw + yd * s + yu * se;
-    r.off += xl * rn + xd * rc + xu * rs;
-    r.diag += xd * yd;
+#pragma unroll
+  for (int m = 0; m < kMaxTerms; ++m) {
+    if (m < w.nterms) {
+      const double* X = w.X[m] + i;
+      const double* Y = w.Y[m] + j;
+      const double xl = X[0], xd = X[g], xu = X[2 * g];
+      const double yl = Y[0], yd = Y[g], yu = Y[2 * g];
+      const double rn = yl * nw + yd * n + yu * ne;
+      const double rc = yl * wv + yu * e;
+      const double rs = yl * sw + yd * s + yu * se;
+      r.off += xl * rn + xd * rc + xu * rs;
+      r.diag += xd * yd;
+    }
   }
   return r;
 }
 
-// nu sweeps on level l (V in LDS, in place for the caller): weighted Jacobi through the scratch array, or four-colour
+// nu sweeps on a level (V in LDS, in place for the caller): weighted Jacobi through the scratch array, or four-colour
 // Gauss-Seidel in the order (0,1),(1,0),(0,0),(1,1) of kernels_stencil.hip
-__device__ void tail_smooth(double* sm, const Layout& L, int l, int kind, int nu, double omega, double mu) {
-  const int g = L.g(l), n = g * g;
-  double* V = sm + L.v(l);
-  const double* F = sm + L.f(l);
+__device__ void tail_smooth(const View& w, double* scratch, int kind, int nu, double omega, double mu) {
+  const int g = w.g, n = g * g;
+  const int shift = 31 - __builtin_clz(g);  // g is a power of two
+  double* V = w.V;
+  const double* F = w.F;
   if (kind == MGCMT_WJACOBI) {
     double* cur = V;
-    double* nxt = sm + L.t();
+    double* nxt = scratch;
     for (int it = 0; it < nu; ++it) {
       for (int p = threadIdx.x; p < n; p += kTailThreads) {
-        const int i = p / g, j = p - i * g;
-        const Point pt = tail_point(sm, L, l, cur, i, j);
+        const int i = p >> shift, j = p & (g - 1);
+        const Point pt = tail_point(w, cur, i, j);
         const double d = pt.diag - mu;
         const double vc = cur[p];
         nxt[p] = vc + omega * ((F[p] - (pt.off + d * vc)) / d);
@@ -91,18 +120,16 @@ __device__ void tail_smooth(double* sm, const Layout& L, int l, int kind, int nu
     }
     return;
   }
-  const int h = g >> 1 > 0 ? g >> 1 : 1;
+  const int h = g >> 1, hshift = shift - 1;  // g >= 2
   for (int it = 0; it < nu; ++it) {
     for (int c = 0; c < 4; ++c) {
       const int ca = (c == 1 || c == 3) ? 1 : 0, cb = (c == 0 || c == 3) ? 1 : 0;
       for (int p = threadIdx.x; p < h * h; p += kTailThreads) {
-        const int i = 2 * (p / h) + ca, j = 2 * (p % h) + cb;
-        if (i < g && j < g) {
-          const Point pt = tail_point(sm, L, l, V, i, j);
-          const double d = pt.diag - mu;
-          const double vc = V[i * g + j];
-          V[i * g + j] = vc + omega * ((F[i * g + j] - (pt.off + d * vc)) / d);
-        }
+        const int i = 2 * (p >> hshift) + ca, j = 2 * (p & (h - 1)) + cb;
+        const Point pt = tail_point(w, V, i, j);
+        const double d = pt.diag - mu;
+        const double vc = V[i * g + j];
+        V[i * g + j] = vc + omega * ((F[i * g + j] - (pt.off + d * vc)) / d);
       }
       __syncthreads();
     }
@@ -133,21 +160,26 @@ __global__ void __launch_bounds__(kTailThreads) k_tail(TailArgs a) {
     }
   }
   __syncthreads();
+  double* scratch = sm + L.t();
   for (int l = 0; l + 1 < L.nlev; ++l) {
-    const int g = L.g(l), gc = g >> 1;
-    tail_smooth(sm, L, l, a.kind, a.nu, a.omega, mu);
+    const View w = make_view(sm, L, l);
+    const int g = w.g, gc = g >> 1;
+    const int shift = 31 - __builtin_clz(g);
+    tail_smooth(w, scratch, a.kind, a.nu, a.omega, mu);
     // residual into the scratch array, then full weighting (rows / columns 2I..2I+2, weights 1/4 1/2 1/4)
-    double* R = sm + L.t();
-    const double* V = sm + L.v(l);
-    const double* F = sm + L.f(l);
+    double* R = scratch;
+    const double* V = w.V;
+    const double* F = w.F;
     for (int p = threadIdx.x; p < g * g; p += kTailThreads) {
-      const int i = p / g, j = p - i * g;
-      const Point pt = tail_point(sm, L, l, V, i, j);
+      const int i = p >> shift, j = p & (g - 1);
+      const Point pt = tail_point(w, V, i, j);
       R[p] = F[p] - (pt.off + (pt.diag - mu) * V[p]);
     }
     __syncthreads();
+    double* Fc = sm + L.f(l + 1);
+    double* Vc = sm + L.v(l + 1);
     for (int p = threadIdx.x; p < gc * gc; p += kTailThreads) {
-      const int I = p / gc, J = p - I * gc;
+      const int I = p >> (shift - 1), J = p & (gc - 1);
       const int j0 = 2 * J;
       const bool h2 = j0 + 2 < g;
       double rows[3];
@@ -160,30 +192,42 @@ __global__ void __launch_bounds__(kTailThreads) k_tail(TailArgs a) {
           rows[r] = 0.0;
         }
       }
-      sm[L.f(l + 1) + p] = 0.25 * rows[0] + 0.5 * rows[1] + 0.25 * rows[2];
-      sm[L.v(l + 1) + p] = 0.0;
+      Fc[p] = 0.25 * rows[0] + 0.5 * rows[1] + 0.25 * rows[2];
+      Vc[p] = 0.0;
     }
     __syncthreads();
   }
   {  // coarsest grid: x = (A - mu I)^-1 f with the explicit inverse (row i contiguous)
+    // (16 lanes share a row; the partial sums meet in a fixed order, so the result does not depend on scheduling)
     const int l = L.nlev - 1, n = L.g(l) * L.g(l);
     const double* inv = a.inv + q * a.inv_stride;
     const double* F = sm + L.f(l);
-    for (int i = threadIdx.x; i < n; i += kTailThreads) {
-      const double* row = inv + (long)i * n;
+    double* Vl = sm + L.v(l);
+    const int sub = threadIdx.x & 15;
+    for (int i0 = 0; i0 < n; i0 += kTailThreads / 16) {  // (every thread makes the same number of trips)
+      const int i = i0 + (threadIdx.x >> 4);
       double acc = 0.0;
-      for (int j = 0; j < n; ++j) acc += row[j] * F[j];
-      sm[L.v(l) + i] = acc;
+      if (i < n) {
+        const double* row = inv + (long)i * n;
+        for (int j = sub; j < n; j += 16) acc += row[j] * F[j];
+      }
+      acc += __shfl_xor(acc, 8);
+      acc += __shfl_xor(acc, 4);
+      acc += __shfl_xor(acc, 2);
+      acc += __shfl_xor(acc, 1);
+      if (sub == 0 && i < n) Vl[i] = acc;
     }
     __syncthreads();
   }
   for (int l = L.nlev - 2; l >= 0; --l) {
-    const int g = L.g(l), gc = g >> 1;
-    double* V = sm + L.v(l);
+    const View w = make_view(sm, L, l);
+    const int g = w.g, gc = g >> 1;
+    const int shift = 31 - __builtin_clz(g);
+    double* V = w.V;
     const double* C = sm + L.v(l + 1);
     // V += P C: odd fine index takes c[(k-1)/2], even the mean of c[k/2-1] and c[k/2] (c[-1] = 0)
     for (int p = threadIdx.x; p < g * g; p += kTailThreads) {
-      const int i = p / g, j = p - i * g;
+      const int i = p >> shift, j = p & (g - 1);
       const int I = i >> 1, J = j >> 1;
       const bool jodd = j & 1;
       const double* r1 = C + I * gc;
@@ -200,7 +244,7 @@ __global__ void __launch_bounds__(kTailThreads) k_tail(TailArgs a) {
       V[p] += val;
     }
     __syncthreads();
-    tail_smooth(sm, L, l, a.kind, a.nu, a.omega, mu);
+    tail_smooth(w, scratch, a.kind, a.nu, a.omega, mu);
   }
   {
     const int n = L.g0 * L.g0;

@@ -98,7 +98,7 @@ void launch_gram(hipStream_t s, long n, const double* const* v, int nv, double* 
 void launch_lincomb(hipStream_t s, long n, const double* const* v, const double* c, int nt, double* dst);
 bool mgs_small_fits(long n);
 
-// the levels of at most 64 x 64 points of a V-cycle in one launch (kernels_tail.hip)
+// the levels of at most 32 x 32 points of a V-cycle in one launch (kernels_tail.hip)
 constexpr int kTailMaxLevels = 6;
 struct TailArgs {
   int g0, nlev, nterms;       // entry grid (g0 x g0), number of levels, Kronecker terms per level

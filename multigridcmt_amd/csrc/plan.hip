@@ -132,7 +132,7 @@ struct mgcmt_plan {
   std::vector<double> h_shifts;
   bool has_mass = false;
   bool use_fused = true;
-  bool use_tail = true;   // levels of at most 64 x 64 points as one launch (kernels_tail.hip)
+  bool use_tail = true;   // levels of at most 32 x 32 points as one launch (kernels_tail.hip)
   bool use_recompute = true;  // down-leg passes skip storing V', up-leg passes recompute it (fused_kernel.h)
   bool force_recompute = false;  // ... on every fused level, not only the bandwidth-bound ones (tests)
   // HIP-graph replay of whole cycles (mgcmt_vcycle): the launch sequence of a cycle is fixed by its
@@ -612,7 +612,7 @@ int ensure_coarse_factor(mgcmt_plan* p, int l, int k, hipStream_t s) {
   return post_launch();
 }
 
-// First level of the cycle's tail: the levels of at most 64 x 64 points below the level the cycle starts on run as
+// First level of the cycle's tail: the levels of at most 32 x 32 points below the level the cycle starts on run as
 // ONE launch (kernels_tail.hip).  -1: no tail (1-D, strips, lexicographic smoothers, Gram-Schmidt between the levels,
 // a coarsest grid too large for the explicit inverse, or nothing to gain).
 int tail_level(const mgcmt_plan* p, int level, int kind, int nu_coarse, int gram_schmidt) {
