@@ -218,7 +218,7 @@ def test_potential_well_operator_three_terms(backend):
 def test_cycle_tail_in_one_launch(backend, kind, omega):
     """MGCMT_OPT_TAIL: the levels of at most 32 x 32 points (coarse solve included) as one LDS-resident launch give
     the cycle of the level-by-level launches — several vectors with their own shifts, coarsest grids 8 and 2, a cycle
-    that starts on a 32 x 32 grid, and the three-term operator of a square well."""
+    that starts right above the tail (64 x 64), and the three-term operator of a square well."""
     from multigridcmt_amd.operators import potential_well_operator
     rng = np.random.RandomState(3)
     cases = [(laplacian_operator(256, "2d") * SCALE, 8, 3), (laplacian_operator(128, "2d") * SCALE, 2, 1),
