@@ -53,6 +53,27 @@ def test_config2_4096_fused_equals_unfused_and_converges(hip_only, kind, omega):
     assert abs(ro[4] / ro[3] - factors[3]) < 0.05
 
 
+@pytest.mark.parametrize("kind,omega", [(_lib.WJACOBI, 2. / 3.), (_lib.GS_MC, 1.0)])
+def test_config3_16384_cycle_fused_equals_unfused(hip_only, kind, omega):
+    """The headline configuration itself: one V(2,2) cycle at 16384^2 through every optimised path (fused passes,
+    recompute instead of store, in-place colour windows, the LDS tail, graph capture) against the same cycle through
+    the one-launch-per-operation kernels."""
+    g = 16384
+    f = np.random.RandomState(6).rand(g * g)
+    outs = []
+    for fused in (1, 0):
+        p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
+        p.set_option(_lib.OPT_FUSED, fused)
+        p.set_shifts([0.0])
+        p.upload(0, _lib.SLOT_F, 0, f)
+        p.fill(0, _lib.SLOT_V, 0, 0.0)
+        for _ in range(2):                       # the second call replays the captured graph
+            p.vcycle(2, 2, kind, omega=omega, nu_coarse=2)
+        outs.append(p.download(0, _lib.SLOT_V, 0))
+        p.close()
+    assert rel_err(outs[0], outs[1]) < 1e-10
+
+
 def test_config3_16384_jacobi_linearity(hip_only):
     """wjacobi with f = 0 is linear: S(a x + b y) = a S(x) + b S(y), checked at the headline size."""
     g = 16384
