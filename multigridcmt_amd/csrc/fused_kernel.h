@@ -412,6 +412,8 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// (Asking the compiler for more waves per SIMD through the second launch-bound argument was measured: with 3 or 4 it
+// spills the windows to scratch and the cycle takes 2-3x as long.  The register counts it picks on its own are right.)
 template <class OP, int KIND, int NSWEEP, int FLAGS>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   using Shape = FusedShape<OP, KIND, NSWEEP, FLAGS>;

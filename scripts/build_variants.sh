@@ -2,4 +2,5 @@ set -e
 cd "$(dirname "$0")/../multigridcmt_amd/csrc"
 rm -rf ../../build/variants ../../variants; mkdir -p ../../build/variants ../../variants
 build() { name=$1; shift; make -s -j8 OUT=$PWD/../../variants/lib_$name.so OBJDIR=$PWD/../../build/variants/obj_$name "$@"; echo built $name; }
-build wide_nostore EXTRA=-DMGCMT_FUSED_NARROW_NOSTORE=0
+build minwaves4 EXTRA=-DMGCMT_FUSED_MINWAVES=4
+build minwaves3 EXTRA=-DMGCMT_FUSED_MINWAVES=3
