@@ -57,8 +57,9 @@ class ShardedPlan:
         nlev_total = _log2(g // lowest) + 1
         if switch_grid is None:
             # below this grid the cycle is cheaper run whole on every rank than as strips with two more exchanges per
-            # level: 2048^2 costs 0.2 ms, 4096^2 0.34 ms on one GPU, an exchange ~0.1 ms of enqueue + latency
-            switch_grid = max(2048, 512 * world)
+            # level: a 2048^2 cycle costs 0.2 ms on one GPU and its all-gather moves 32 MiB; one level up it would be
+            # 0.34 ms and 128 MiB (~0.3 ms over xGMI), more than the two exchanges (~0.1 ms each) it saves
+            switch_grid = max(2048, 64 * world)
         # strip levels: grids above the switch size; every strip must keep >= 2*HALO_ROWS rows and even bounds
         ls = 0
         while ls < nlev_total - 1 and (g >> ls) > switch_grid and ((g >> ls) // world) >= 4 * HALO_ROWS:
