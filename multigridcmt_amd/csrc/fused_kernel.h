@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
           if constexpr (NINE) {
             const double n[3] = {Wl[nl], Wa[cn], Wb[cn]}, c[3] = {Wl[cl], ca, cb}, so[3] = {Wl[sl], Wa[cs], Wb[cs]};
             op.template eval<0>(n, c, so, off, dg, inv);
-            if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<0>(c, off, dg, inv);
+            if (OP::kSpecialRow && CHK && op.special_row(rs)) op.template fix_special<0>(c, off, dg, inv);
           } else {
             const double left = MGCMT_FETCH_LEFT(lane_up, cb);
             const double n[3] = {0.0, Wa[cn], 0.0}, c[3] = {left, ca, cb}, so[3] = {0.0, Wa[cs], 0.0};
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
           if constexpr (NINE) {
             const double n[3] = {Wa[cn], Wb[cn], Wr[nl]}, c[3] = {ca, cb, Wr[cl]}, so[3] = {Wa[cs], Wb[cs], Wr[sl]};
             op.template eval<1>(n, c, so, off, dg, inv);
-            if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<1>(c, off, dg, inv);
+            if (OP::kSpecialRow && CHK && op.special_row(rs)) op.template fix_special<1>(c, off, dg, inv);
           } else {
             const double right = MGCMT_FETCH_RIGHT(lane_dn, ca);
             const double n[3] = {0.0, Wb[cn], 0.0}, c[3] = {ca, cb, right}, so[3] = {0.0, Wb[cs], 0.0};
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
           if constexpr (NINE) {
             const double n[3] = {wl[sw][sa], wa[s][sa], wb[s][sa]}, c[3] = {wl[sw][sc], ca, cb}, so[3] = {wl[sw][sn], wa[s][sn], wb[s][sn]};
             op.template eval<0>(n, c, so, off, dg, inv);
-            if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<0>(c, off, dg, inv);
+            if (OP::kSpecialRow && CHK && op.special_row(rs)) op.template fix_special<0>(c, off, dg, inv);
           } else {
             const double left = MGCMT_FETCH_LEFT(lane_up, cb);
             const double n[3] = {0.0, wa[s][sa], 0.0}, c[3] = {left, ca, cb}, so[3] = {0.0, wa[s][sn], 0.0};
@@ -762,7 +762,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
           if constexpr (NINE) {
             const double n[3] = {wa[s][sa], wb[s][sa], wr[sw][sa]}, c[3] = {ca, cb, wr[sw][sc]}, so[3] = {wa[s][sn], wb[s][sn], wr[sw][sn]};
             op.template eval<1>(n, c, so, off, dg, inv);
-            if (OP::kSpecialRow && op.special_row(rs)) op.template fix_special<1>(c, off, dg, inv);
+            if (OP::kSpecialRow && CHK && op.special_row(rs)) op.template fix_special<1>(c, off, dg, inv);
           } else {
             const double right = MGCMT_FETCH_RIGHT(lane_dn, ca);
             const double n[3] = {0.0, wb[s][sa], 0.0}, c[3] = {ca, cb, right}, so[3] = {0.0, wb[s][sn], 0.0};
@@ -854,7 +854,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   // iterations before and after, the outer two-trip loop only exists so that its code is emitted once.
   constexpr bool kFastBody = !OP::kBigBody || B == 6;
   const int fast_lo = r_begin + S + XL + 3;
-  const int fast_hi = (r_end + S + XL < row_hi ? r_end + S + XL : row_hi) - (B - 1);
+  int fast_hi = (r_end + S + XL < row_hi ? r_end + S + XL : row_hi) - (B - 1);
+  // ... and, for policies that patch the operator's last row, no stage on that row: the steady-state body then has
+  // no trace of the patch (left in, the compiler turns its uniform branch into selects on every evaluation)
+  if (OP::kSpecialRow && fast_hi > (int)a.last_row - (B - 1)) fast_hi = (int)a.last_row - (B - 1);
   int base = rstart;
   if constexpr (kFastBody) {
 #pragma nounroll
