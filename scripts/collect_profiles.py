@@ -37,6 +37,23 @@ for sm, kname in KERNEL.items():
         "algorithmic_bytes_24B_per_update": 24 * n * n * 2, "bytes_one_pass_reads_v_f_writes_v": 24 * n * n,
         "note": "one launch = 2 sweeps; HBM bytes per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 16-byte streams at half)"}
     table["%s_%d" % (sm, n)] = fetch + write
+# the other fine-level kernels of the cycle (same PMC passes): HBM bytes per launch next to their algorithmic bytes
+OTHER = {"wjacobi": {"k_fused<mgcmt::fused::Op5, 0, 2, 10>": ("down pass: 2 sweeps + residual + restriction, V' not stored", 16 + 2),
+                     "k_fused<mgcmt::fused::Op5, 0, 2, 33>": ("up pass: 2 recomputed sweeps + correction + 2 sweeps", 24 + 2)},
+         "rb": {"k_fused<mgcmt::fused::Op5, 1, 2, 10>": ("down pass: 2 sweeps + residual + restriction, V' not stored", 16 + 2),
+                "k_fused<mgcmt::fused::Op5, 1, 2, 33>": ("up pass: 2 recomputed sweeps + correction + 2 sweeps", 24 + 2)}}
+for sm, kernels in OTHER.items():
+    for kname, (what, bpp) in kernels.items():
+        vals = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            files = sorted(glob.glob(os.path.join(g, "pmc_%s_%s_%s" % (tag, sm, counter), "**", "*counter_collection.csv"), recursive=True),
+                           key=os.path.getmtime)[-1:]
+            acc = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
+                   if kname in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            vals[counter] = sum(acc) / len(acc) if acc else None
+        if vals["FETCH_SIZE"] is not None and vals["WRITE_SIZE"] is not None:
+            detail["%s_%d %s" % (sm, n, kname)] = {"what": what, "fetch_bytes_corrected_x2": vals["FETCH_SIZE"] * 2048,
+                                                  "write_bytes": vals["WRITE_SIZE"] * 1024, "algorithmic_bytes": bpp * n * n}
 if table:
     json.dump(table, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     json.dump(detail, open(os.path.join(out, "%s_pmc_traffic_detail.json" % prefix), "w"), indent=1)
