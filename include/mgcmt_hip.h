@@ -171,6 +171,9 @@ typedef enum mgcmt_option {
   MGCMT_OPT_RECOMPUTE = 3,  /* default 1: on levels of >= 2^22 points down-leg passes do not store the pre-smoothed iterate and
                                up-leg passes recompute it; 2: on every fused level; 0: never */
   MGCMT_OPT_GRAPH = 2,      /* default 1: mgcmt_vcycle replays its launch sequence as a HIP graph from the second call on */
+  MGCMT_OPT_WIDE = 5,       /* default 0 (measured slower so far); 1: weighted-Jacobi passes on 5-point levels of >= 2048 columns use
+                               256-column windows (two 128-column halves per wave: half the overlap reads); 2: from 256 columns on
+                               (tests).  Process-wide. */
   MGCMT_OPT_TAIL = 4        /* default 1: the 2-D levels of at most 32 x 32 points below a cycle's top level, coarse solve
                                included, run as ONE launch out of LDS (needs MGCMT_OPT_FUSED; not with Gram-Schmidt) */
 } mgcmt_option;

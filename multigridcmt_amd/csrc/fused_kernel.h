@@ -124,12 +124,17 @@ __device__ __forceinline__ double lane_shift(double v) {
   const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-// value of the left neighbour (lane - 1): wave_shr:1; of the right neighbour (lane + 1): wave_shl:1
+// value of the left neighbour (lane - 1): wave_shr:1; of the right neighbour (lane + 1): wave_shl:1; the _ROT forms
+// wrap around the wave (wave_ror:1 / wave_rol:1; the address versions take (lane -/+ 1) mod 64)
 #define MGCMT_FETCH_LEFT(addr, v) lane_shift<0x138>(v)
 #define MGCMT_FETCH_RIGHT(addr, v) lane_shift<0x130>(v)
+#define MGCMT_FETCH_LEFT_ROT(addr, v) lane_shift<0x13C>(v)
+#define MGCMT_FETCH_RIGHT_ROT(addr, v) lane_shift<0x134>(v)
 #else
 #define MGCMT_FETCH_LEFT(addr, v) lane_fetch_addr(addr, v)
 #define MGCMT_FETCH_RIGHT(addr, v) lane_fetch_addr(addr, v)
+#define MGCMT_FETCH_LEFT_ROT(addr, v) lane_fetch_addr(addr, v)
+#define MGCMT_FETCH_RIGHT_ROT(addr, v) lane_fetch_addr(addr, v)
 #endif
 
 // Arithmetic note: multiply-adds are written as explicit fma() (fewer VALU issues; measured -10 % on a 4096^2
@@ -967,5 +972,6 @@ void launch_fused_op9c(hipStream_t s, const fused::FusedArgs& a, int multicolour
 void launch_fused_op9(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);    // two terms
 void launch_fused_op9m3(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);  // three terms
 void launch_fused_op5v(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);   // 5-point + product potential
+bool launch_fused_wide(hipStream_t s, const fused::FusedArgs& a, int nsweep, int flags, int k);  // 5-point Jacobi, 256-column windows
 
 }  // namespace mgcmt

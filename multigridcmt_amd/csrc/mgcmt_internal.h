@@ -68,7 +68,8 @@ void launch_lex_sweep(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doub
 bool fused_supported(const KGrid& g, const KOp& op);
 int fused_max_sweeps(const KOp& op, int multicolour, bool strip);
 int fused_max_recompute(const KOp& op, int multicolour, int nsweep);
-void fused_set_rows(long rows);  // tuning: rows per chunk, 0 = automatic
+void fused_set_rows(long rows);
+void fused_set_wide(int mode);  // tuning: rows per chunk, 0 = automatic
 void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
                   double omega, int multicolour, int nsweep, int mode, int npre, long row_lo, long row_hi, long last_row, int k);
 

@@ -1195,6 +1195,11 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
     p->use_graph = value != 0;
     return MGCMT_OK;
   }
+  if (option == MGCMT_OPT_WIDE) {
+    fused_set_wide(value);  // process-wide, like the rows knob
+    p->graphs_invalidate();
+    return MGCMT_OK;
+  }
   if (option == MGCMT_OPT_TAIL) {
     p->use_tail = value != 0;
     p->graphs_invalidate();
