@@ -109,6 +109,8 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;  // valid on lane 0
 }
 
+// VEC2: 16-byte accesses (n even, 16-byte aligned columns) — the pass is pure streaming
+template <bool VEC2>
 __global__ void __launch_bounds__(kRedThreads) k_mgs_step(long n, const double* __restrict__ pin, int nb_in, double* __restrict__ u, long stride,
                                                           int m, double* __restrict__ pout) {
   constexpr int kWaves = kRedThreads / 64;
@@ -134,20 +136,43 @@ __global__ void __launch_bounds__(kRedThreads) k_mgs_step(long n, const double* 
     c[t] = t < m ? s_sum[t + 1] / s0 : 0.0;
     acc[t] = 0.0;
   }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const double ue = u[i];
-    double first = 0.0;
+  if (VEC2) {
+    double2* u2 = reinterpret_cast<double2*>(u);
+    const long n2 = n >> 1, stride2 = stride >> 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+      const double2 ue = u2[i];
+      double2 first = make_double2(0.0, 0.0);
 #pragma unroll
-    for (int t = 0; t < kMaxVec; ++t) {
-      if (t < m) {  // uniform
-        double* at = u + (long)(t + 1) * stride;
-        const double a = at[i] - c[t] * ue;
-        at[i] = a;
-        if (t == 0) first = a;
-        acc[t] += first * a;
+      for (int t = 0; t < kMaxVec; ++t) {
+        if (t < m) {  // uniform
+          double2* at = u2 + (long)(t + 1) * stride2;
+          double2 a = at[i];
+          a.x -= c[t] * ue.x;
+          a.y -= c[t] * ue.y;
+          at[i] = a;
+          if (t == 0) first = a;
+          acc[t] += first.x * a.x;
+          acc[t] += first.y * a.y;
+        }
       }
+      u2[i] = make_double2(ue.x / nrm, ue.y / nrm);
     }
-    u[i] = ue / nrm;
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+      const double ue = u[i];
+      double first = 0.0;
+#pragma unroll
+      for (int t = 0; t < kMaxVec; ++t) {
+        if (t < m) {  // uniform
+          double* at = u + (long)(t + 1) * stride;
+          const double a = at[i] - c[t] * ue;
+          at[i] = a;
+          if (t == 0) first = a;
+          acc[t] += first * a;
+        }
+      }
+      u[i] = ue / nrm;
+    }
   }
 #pragma unroll
   for (int t = 0; t < kMaxVec; ++t) {
@@ -406,7 +431,9 @@ void launch_mgs_small(hipStream_t s, long n, double* a0, long stride, int k) {
 
 void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out) {
   const int nb = reduce_blocks(n);
-  hipLaunchKernelGGL(k_mgs_step, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb, u, stride, m, partials_out);
+  const bool vec2 = (n & 1) == 0 && (stride & 1) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0;
+  if (vec2) hipLaunchKernelGGL(k_mgs_step<true>, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb, u, stride, m, partials_out);
+  else hipLaunchKernelGGL(k_mgs_step<false>, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb, u, stride, m, partials_out);
 }
 
 void launch_dots(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, double* out) {
