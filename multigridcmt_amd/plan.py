@@ -100,6 +100,12 @@ class Plan:
         check(_lib.lib().mgcmt_download(self._h, level, slot, vec, as_dp(out), out.size, stream))
         return out
 
+    def download_into(self, level, slot, vec, out, stream=None):
+        """Like download, into a caller-provided contiguous float64 array of the level's size."""
+        if not (out.flags.c_contiguous and out.dtype == np.float64 and out.size == self.size(level)):
+            raise ValueError("download_into needs a contiguous float64 array of the level's size")
+        check(_lib.lib().mgcmt_download(self._h, level, slot, vec, as_dp(out), out.size, stream))
+
     def fill(self, level, slot, vec, value, stream=None):
         check(_lib.lib().mgcmt_fill(self._h, level, slot, vec, c_double(value), stream))
 

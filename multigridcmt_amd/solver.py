@@ -232,14 +232,20 @@ class MGCMTSolver:
         op = recognise(A, dimension)
         plan = get_plan(op, int(lowest_level), nvec=k)
         plan.set_shifts(shifts)
+        zero_start = not v0_matrix.any()          # the reference's callers pass zeros (1DPotMatrixVcycle.py:70): nothing to upload
         for i in range(k):
-            plan.upload(0, SLOT_V, i, v0_matrix[:, i])
+            if zero_start:
+                plan.zero(0, SLOT_V, i)
+            else:
+                plan.upload(0, SLOT_V, i, v0_matrix[:, i])
             plan.upload(0, SLOT_F, i, f_matrix[:, i])
         plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=k, nu_coarse=int(nu_coarse), gram_schmidt=True)
-        v = np.zeros((n, k))
+        # columns are downloaded as contiguous rows of a (k, n) array; the (n, k) result is its transpose (a
+        # column-major array: the same values and indexing as the reference's, without k strided scatters on the host)
+        rows = np.empty((k, n))
         for i in range(k):
-            v[:, i] = plan.download(0, SLOT_V, i)
-        return v
+            plan.download_into(0, SLOT_V, i, rows[i])
+        return rows.T
 
     # ------------------------------------------------------------------------------------------
     # grid transfers as stand-alone calls (addition; the stale drivers main.py:81,163 and
