@@ -98,3 +98,30 @@ def test_structured_operator_algebra():
     assert np.allclose(op.shifted(2.0).toarray(), (sm.laplacian(8, dimension="2d") - 2.0 * sp.eye(64)).toarray())
     assert np.allclose(op.diagonal(), sm.laplacian(8, dimension="2d").diagonal())
     assert isinstance(sm.laplacian(8, dimension="2d", matrix_free=True), StructuredOperator)
+
+
+def test_bench_line_contract(capsys, monkeypatch):
+    """bench.py's one JSON line carries every field of the driver's contract (run here on a tiny grid through the
+    emulated kernels: the numbers mean nothing, the shape of the line is what is checked)."""
+    import json
+    import sys
+    from conftest import ROOT, bind_backend
+    bind_backend("emu")
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--grid", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    bench.main()
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["dtype"] == "f64" and out["vs_baseline"] is None
+    assert out["unit"] == "MLUPS" and out["higher_is_better"] is True and "workload" in out["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in out["roofline"], key
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0
+    assert abs(out["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-12
+    assert len(out["residual_reduction_per_cycle"]) == 10 and out["residual_reduction_per_cycle"][-1] < 1e-3
