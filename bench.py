@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
+    ap.add_argument("--switch-grid", type=int, default=None, help="multi-GPU: grid below which every rank runs the whole problem")
     ap.add_argument("--config", type=int, choices=[1, 2, 3], default=None,
                     help="a BASELINE.json config by index: 1 = 4096^2 V(2,2) red-black, 2 = 16384^2 weighted Jacobi (the default, "
                          "the one `metric` is quoted on), 3 = 32768^2 V(2,2) red-black (the multi-GPU config; fits one GPU too)")

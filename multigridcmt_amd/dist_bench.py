@@ -7,7 +7,9 @@ import time
 import numpy as np
 
 
-def run(args):
+def run(args, backend="nccl", on_gpu=True):
+    """backend / on_gpu exist for the CPU rehearsal of this very function (tests/test_distributed.py: gloo, host memory,
+    emulated kernels); bench.py always calls it with the defaults."""
     import torch
     import torch.distributed as dist
     from . import _lib
@@ -19,13 +21,16 @@ def run(args):
     os.environ.setdefault("MASTER_PORT", "29533")
     local = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if on_gpu:
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     g = args.grid
     kind = _lib.WJACOBI if args.smoother == "wjacobi" else _lib.GS_MC
     omega = 2.0 / 3.0 if args.smoother == "wjacobi" else 1.0
     op = laplacian_operator(g, "2d") * (-1.0 / np.pi ** 2)
-    sp = ShardedPlan(op, args.lowest, rank, world, device=local)
+    sp = ShardedPlan(op, args.lowest, rank, world, device=local, switch_grid=getattr(args, "switch_grid", None), on_gpu=on_gpu)
     sp.set_shift(0.0)
     rows = g // world
     f = np.random.RandomState(1 + rank).rand(rows * g)
@@ -38,16 +43,19 @@ def run(args):
 
     for _ in range(args.warmup):
         cycle()
-    sp.sync()
-    torch.cuda.synchronize()
+    def device_sync():
+        sp.sync()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    device_sync()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         cycle()
-    sp.sync()
-    torch.cuda.synchronize()
+    device_sync()
     dist.barrier()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda:%d" % local)
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=("cuda:%d" % local) if on_gpu else "cpu")
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     n = float(g) * g

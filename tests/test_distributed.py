@@ -82,3 +82,40 @@ def test_sharded_cycle_equals_single_plan(tmp_path, world, kind_name, force_reco
     p.close()
     assert rel_err(got, want) < 1e-12
     assert abs(res - want_res) < 1e-9 * want_res
+
+
+def _bench_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hip_cpu_mock")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import argparse
+    import contextlib
+    import io
+    import build_emu
+    from multigridcmt_amd import _lib, dist_bench
+    _lib.use_library(build_emu.build())
+    args = argparse.Namespace(grid=512, smoother="rb", nu=2, lowest=8, steps=2, warmup=1, switch_grid=128, gpus=world)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        dist_bench.run(args, backend="gloo", on_gpu=False)
+    with open(os.path.join(out_dir, "out%d.txt" % rank), "w") as fh:
+        fh.write(buf.getvalue())
+
+
+def test_multi_rank_bench_line(tmp_path):
+    """bench.py's multi-GPU leg (multigridcmt_amd/dist_bench.py) rehearsed with two gloo ranks on host memory: barrier-
+    bracketed timing, maximum over ranks, ONE JSON line from rank 0 with the contract's fields."""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_bench_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    out0 = (tmp_path / "out0.txt").read_text()
+    assert (tmp_path / "out1.txt").read_text().strip() == ""
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong" and out["config"]["strip_levels"] == 2
+    assert out["value"] > 0 and abs(out["value"] - 512 * 512 * 4 * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6) < 1e-6 * out["value"]
