@@ -514,6 +514,8 @@ int down_leg(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, bool z
     const int rmax = fused_max_recompute(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0, pass_sweeps(p, l, kind, nu_up));
     // worth it where the level is bandwidth-bound; on small levels the longer pipeline of the up-leg pass costs more
     // latency than the saved traffic is worth (measured: 1024^2 cycle 0.148 -> 0.179 ms with it)
+    // (the same threshold serves the 9-point Galerkin levels: measured at 16384^2, recompute off on them costs 0.26 ms
+    // per cycle, thresholds of 2^20 and 2^18 points are within noise of / slower than 2^22)
     const bool big = p->force_recompute || p->interior(l) >= (1L << 22);
     if (recompute && p->use_recompute && big && left <= rmax) {
       MG_TRY(fused_pass(p, l, kind, left, omega, 2 | 8 | zi, k, s));
