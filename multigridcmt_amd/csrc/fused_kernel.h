@@ -455,6 +455,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   if (group >= a.n_col_groups) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lane_up = (lane > 0 ? lane - 1 : 0) << 2, lane_dn = (lane < 63 ? lane + 1 : 63) << 2;  // left / right neighbour
+  (void)lane_up;  // (only the ds_bpermute form of the lane reads takes the addresses)
+  (void)lane_dn;
   const int strip = group * kWavesPerBlock + wave;
   const int nc = (int)a.nc, nr = (int)a.nr, cnc = (int)a.cnc;
   const int row_lo = (int)a.row_lo, row_hi = (int)a.row_hi;
