@@ -2,17 +2,24 @@
 
     python bench.py --gpus 1 --steps K --warmup W            (one MI355X)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...                             (no launcher: starts the N ranks itself)
 
-One "step" is one V(2,2) cycle of the hot path on a resident right-hand side (BASELINE.json
-configs[2]: 2-D Laplacian 16384^2 fp64, weighted-Jacobi smoother; the cycle descends to an 8 x 8
-direct solve as the reference's 2-D drivers do, 2DPotMatrixVcycle.py:95).  `value` is fine-grid MLUPS =
-grid points x fine-level sweeps per cycle x cycles / wall time of the whole cycles (all levels, transfers
-and the coarse solve included), so it is a lower bound on the fine smoother's own rate, which is reported
-separately in `roofline` from HIP events around the fine-level sweeps alone.
+N = 1: one "step" is one V(2,2) cycle of the hot path on a resident right-hand side (BASELINE.json configs[2]:
+2-D Laplacian 16384^2 fp64, weighted-Jacobi smoother; the cycle descends to an 8 x 8 direct solve as the
+reference's 2-D drivers do, 2DPotMatrixVcycle.py:95).  `value` is fine-grid MLUPS = grid points x fine-level sweeps
+per cycle x cycles / wall time of the whole cycles (all levels, transfers and the coarse solve included), so it is a
+lower bound on the fine smoother's own rate, which `roofline` reports from HIP events around the fine-level passes
+alone.  The same line also carries the red-black pass (`roofline_rb`, north_star's target kernel), the
+reference-faithful cycle (V(4,4) below the top level, MGCMTSolver.py:320), the red-black cycle, the one-GPU time of
+the multi-GPU configuration (`strong_scaling_base`) and the CPU baselines.
+
+N > 1: BASELINE.json configs[3] — 32768^2, V(2,2) red-black, row strips with RCCL halo exchange (strong scaling:
+the grid is fixed as N grows; multigridcmt_amd/dist_bench.py).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,67 +33,179 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 BYTES_PER_LUP = 24.0           # read v, read f, write v (fp64) per point and sweep
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--grid", type=int, default=16384)
-    ap.add_argument("--smoother", default="wjacobi", choices=["wjacobi", "rb"])
+    ap.add_argument("--grid", type=int, default=None, help="default: 16384 on one GPU, 32768 on several")
+    ap.add_argument("--smoother", default=None, choices=["wjacobi", "rb"], help="default: wjacobi on one GPU, rb on several")
     ap.add_argument("--nu", type=int, default=2, help="pre- and post-smoothing sweeps on every level")
     ap.add_argument("--lowest", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true", help="only the headline cycle and its roofline record")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
     ap.add_argument("--switch-grid", type=int, default=None, help="multi-GPU: grid below which every rank runs the whole problem")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
+                    help="multi-GPU halo exchange: RCCL inside libmgcmt_hip.so (default) or torch.distributed point-to-point")
     ap.add_argument("--config", type=int, choices=[1, 2, 3], default=None,
                     help="a BASELINE.json config by index: 1 = 4096^2 V(2,2) red-black, 2 = 16384^2 weighted Jacobi (the default, "
                          "the one `metric` is quoted on), 3 = 32768^2 V(2,2) red-black (the multi-GPU config; fits one GPU too)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.config is not None:
         args.grid, args.smoother = {1: (4096, "rb"), 2: (16384, "wjacobi"), 3: (32768, "rb")}[args.config]
+    many = args.gpus > 1
+    if args.grid is None:
+        args.grid = 32768 if many else 16384
+    if args.smoother is None:
+        args.smoother = "rb" if many else "wjacobi"
     return args
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has not
+    touched the GPU), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0]
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit("rank exit codes: %s" % codes)
+
+
 def cpu_baseline(args, kind_name):
-    """The oracle's C restatement (oracle/mgcmt_oracle.c) timed on this box's host cores on a bounded
-    sample of the same workload: whole V(2,2) cycles on a smaller grid, scaled per point."""
+    """The oracle's C restatement (oracle/mgcmt_oracle.c) timed on this box's host cores on the SAME workload (whole
+    V(nu,nu) cycles on the full grid while the budget lasts, at least one after the warm-up cycle)."""
     try:
         from oracle import structured
     except Exception as e:                                     # oracle not built: report, do not fail the bench
         return {"value": None, "unit": "MLUPS", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
-    return structured.time_cpu_baseline(kind_name, args.nu, args.lowest, args.cpu_seconds, grid=min(args.grid, 8192),
+    return structured.time_cpu_baseline(kind_name, args.nu, args.lowest, args.cpu_seconds, grid=args.grid,
                                         workload_grid=args.grid)
 
 
-def measured_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the PMC passes of scripts/gpu_pmc.sh (rocprofv3 cannot
-    profile the process it runs in; the summary of that run of this same command is kept under profiles/)."""
+def cpu_reference_equivalent(grid=128):
+    """the reference's own formulation on the host — generic scipy.sparse operators, the smoother's
+    iteration matrix materialised by a sparse solve with a sparse right-hand side (MGCMTSolver.py:193-206), Galerkin
+    products R*A*P on every level of every call (:318) — at the largest size the reference's author could run (128^2,
+    BASELINE.md §1/§2: 23.6 s per V(4,4) cycle measured with the reference itself).  Restated in oracle/sparse_ref.py;
+    the reference's files do not exist on this box.  Next to it the same cycle with O(N) sweeps (the oracle the
+    parity tests use)."""
+    try:
+        from oracle.sparse_ref import RefSolver, RefStencilMaker
+    except Exception as e:
+        return {"value": None, "sample": "unavailable: %s" % e}
+    ref, rsm = RefSolver(), RefStencilMaker()
+    A = (-1 / np.pi ** 2) * rsm.laplacian(grid, dimension="2d")
+    f = np.random.RandomState(1).rand(grid * grid)
+    t0 = time.perf_counter()
+    ref.vcycle(np.zeros(grid * grid), f, A, rsm, nu1=4, nu2=4, dimension="2d", lowest_level=8, smoother=ref.wjacobi_iteration_matrix)
+    t_ref = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref.vcycle(np.zeros(grid * grid), f, A, rsm, nu1=4, nu2=4, dimension="2d", lowest_level=8)
+    t_fast = time.perf_counter() - t0
+    lups = float(grid * grid) * 8
+    return {"value": lups / t_ref / 1e6, "unit": "MLUPS", "cores": 1, "kind": "port",
+            "seconds_per_vcycle": t_ref,
+            "sample": "one V(4,4) weighted-Jacobi cycle on %d^2 (lowest_level 8) in the reference's formulation: scipy.sparse "
+                      "operators, iteration matrix by spsolve with a sparse right-hand side, R*A*P per level "
+                      "(oracle/sparse_ref.py wjacobi_iteration_matrix); single-threaded SciPy" % grid,
+            "same_cycle_O_N_sweeps": {"value": lups / t_fast / 1e6, "seconds_per_vcycle": t_fast,
+                                      "sample": "oracle/sparse_ref.py with one sparse mat-vec per sweep"}}
+
+
+def traffic_record(args, smoother, nsweep):
+    """HBM bytes per launch of the fused fine-level pass from the PMC passes of scripts/gpu_pmc.sh (rocprofv3 cannot
+    profile the process it runs in: the figure comes from a profiled run of this same command, kept under profiles/
+    together with where it came from)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             table = json.load(fh)
-        return table.get("%s_%d" % (args.smoother, args.grid))
+        key = "%s_%d" % (smoother, args.grid)
+        val = table.get(key)
+        if val is None:
+            return None, None
+        src = dict(table.get("_source", {}))
+        src.setdefault("file", "profiles/pmc_traffic.json")
+        src["key"] = key
+        src["measured_in_this_run"] = False
+        return val, src
     except Exception:
-        return None
+        return None, None
 
 
-def main():
-    args = parse()
+def pass_roofline(plan, args, kind, smoother, omega, n, reps=25):
+    """HIP-event timing (on the stream the kernels are launched on, mgcmt_time_smoother) of the fused fine-level
+    pass.  `achieved` / `frac`: the bytes ONE pass over the level has to move (read v, read f, write v' = 24 B per
+    point — what the HBM actually has to deliver, whatever the number of sweeps fused into the pass) per second of
+    launch time; `achieved_algorithmic_24B_per_update` / `frac_algorithmic_24B`: SURVEY §8(d)'s accounting, 24 B per
+    lattice-site UPDATE, which counts the pass's bytes once per fused sweep and so exceeds 1 at fusion depth 2."""
     from multigridcmt_amd import _lib
-    from multigridcmt_amd.operators import laplacian_operator
-    from multigridcmt_amd.plan import Plan
+    fuse = plan.fused_max_sweeps(0, kind)
+    nu = args.nu
+    launches = -(-nu // fuse) if fuse else nu * (1 if kind == _lib.WJACOBI else 4)
+    ms = plan.time_smoother(0, kind, nu, omega, reps)
+    launch_s = ms * 1e-3 / (reps * launches)
+    depth = nu / launches
+    phys = n * BYTES_PER_LUP / launch_s / 1e9
+    algo = n * BYTES_PER_LUP * depth / launch_s / 1e9
+    ms1 = plan.time_smoother(0, kind, 1, omega, reps)              # one sweep per launch
+    one = n * BYTES_PER_LUP / (ms1 * 1e-3 / reps) / 1e9
+    traffic, source = traffic_record(args, smoother, int(depth))
+    rec = {"bound": "hbm",
+           "kernel": "k_fused<Op5,%d,%d,0>: fused fine-level pass, %d %s sweep(s) per launch" % (0 if kind == _lib.WJACOBI else 1, int(depth), int(depth), smoother),
+           "achieved": phys, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": phys / HBM_PEAK_GBS,
+           "bytes_per_launch": n * BYTES_PER_LUP, "avg_launch_ms": launch_s * 1e3,
+           "achieved_algorithmic_24B_per_update": algo, "frac_algorithmic_24B": algo / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": n * BYTES_PER_LUP * depth, "fusion_depth": depth,
+           "single_sweep_per_launch": {"achieved": one, "frac": one / HBM_PEAK_GBS, "avg_launch_ms": ms1 / reps},
+           "smoother_mlups": n * depth / launch_s / 1e6,
+           "traffic": traffic, "traffic_source": source}
+    return rec
+
+
+def time_cycles(plan, steps, warmup, cycle):
+    for _ in range(warmup):
+        cycle()
+    plan.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cycle()
+    plan.sync()
+    return time.perf_counter() - t0
+
+
+def main(argv=None):
+    args = parse(argv)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 or args.force_sharded:
         from multigridcmt_amd import dist_bench
         return dist_bench.run(args)
+    from multigridcmt_amd import _lib
+    from multigridcmt_amd.operators import laplacian_operator
+    from multigridcmt_amd.plan import Plan
 
     g = args.grid
-    kind = _lib.WJACOBI if args.smoother == "wjacobi" else _lib.GS_MC
-    omega = 2.0 / 3.0 if args.smoother == "wjacobi" else 1.0
+    kinds = {"wjacobi": (_lib.WJACOBI, 2.0 / 3.0), "rb": (_lib.GS_MC, 1.0)}
+    kind, omega = kinds[args.smoother]
     op = laplacian_operator(g, "2d") * (-1.0 / np.pi ** 2)
     plan = Plan(op, args.lowest, nvec=1, device=0)
     plan.set_shifts([0.0])
@@ -94,36 +213,16 @@ def main():
     f = rng.rand(g * g)
     plan.upload(0, _lib.SLOT_F, 0, f)
     plan.fill(0, _lib.SLOT_V, 0, 0.0)
-    del f
 
-    def cycle():
-        plan.vcycle(args.nu, args.nu, kind, omega=omega, k=1, nu_coarse=args.nu)
+    def cycle(kind_=kind, omega_=omega, nu_coarse=None):
+        plan.vcycle(args.nu, args.nu, kind_, omega=omega_, k=1, nu_coarse=args.nu if nu_coarse is None else nu_coarse)
 
-    for _ in range(args.warmup):
-        cycle()
-    plan.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cycle()
-    plan.sync()
-    elapsed = time.perf_counter() - t0
+    elapsed = time_cycles(plan, args.steps, args.warmup, cycle)
 
     n = float(g) * g
     sweeps = 2 * args.nu
     value = n * sweeps * args.steps / elapsed / 1e6
-    # dominant kernel: the fine-level smoother sweep, timed alone with HIP events on the same stream
-    # (one launch = one fused pass of up to 2 sweeps: algorithmic bytes per launch = 24 B x points x sweeps in it)
-    reps = 25                      # >= 50 fine-level sweeps at the default nu
-    fuse = plan.fused_max_sweeps(0, kind)
-    launches = -(-args.nu // fuse) if fuse else args.nu * (1 if kind == _lib.WJACOBI else 4)
-    ms = plan.time_smoother(0, kind, args.nu, omega, reps)
-    launch_s = ms * 1e-3 / (reps * launches)
-    sweep_s = ms * 1e-3 / (reps * args.nu)
-    achieved = n * BYTES_PER_LUP / sweep_s / 1e9
-    ms1 = plan.time_smoother(0, kind, 1, omega, reps)              # one sweep per launch: the unfused comparison
-    achieved1 = n * BYTES_PER_LUP / (ms1 * 1e-3 / reps) / 1e9
-    probe = {name: n * bpp / (plan.bandwidth_probe(0, k_, 1024, 5) * 1e-3) / 1e9
-             for k_, name, bpp in ((0, "copy", 16), (1, "triad", 24), (2, "read", 8))}
+    names = {"wjacobi": "weighted-Jacobi (w=2/3)", "rb": "red-black Gauss-Seidel"}
     out = {
         "metric": "fine_grid_mlups_vcycle_2d_laplacian_fp64",
         "value": value,
@@ -138,20 +237,35 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "2D Laplacian %d^2 fp64, V(%d,%d) %s on every level, lowest_level %d, 1xMI355X" %
-                   (g, args.nu, args.nu, "weighted-Jacobi (w=2/3)" if args.smoother == "wjacobi" else "red-black Gauss-Seidel",
-                    args.lowest),
+                   (g, args.nu, args.nu, names[args.smoother], args.lowest),
                    "grid": g, "smoother": args.smoother, "nu1": args.nu, "nu2": args.nu, "lowest_level": args.lowest},
         "vcycles_per_s": args.steps / elapsed,
-        "smoother_mlups": n / sweep_s / 1e6,
-        "roofline": {"bound": "hbm", "kernel": "fused fine-level pass (%d %s sweep(s) per launch)" % (args.nu // launches, args.smoother),
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": n * BYTES_PER_LUP * args.nu / launches, "avg_launch_ms": launch_s * 1e3,
-                     "fusion_depth": args.nu / launches,
-                     "single_sweep_per_launch": {"achieved": achieved1, "frac": achieved1 / HBM_PEAK_GBS},
-                     "measured_ceilings_GBs": probe},
         "device": _lib.device_name(0),
     }
-    out["roofline"]["traffic"] = measured_traffic(args)
+    # dominant kernel: the fused fine-level pass of the timed smoother
+    out["roofline"] = pass_roofline(plan, args, kind, args.smoother, omega, n)
+    out["smoother_mlups"] = out["roofline"]["smoother_mlups"]
+    out["roofline"]["measured_ceilings_GBs"] = {
+        name: n * bpp / (plan.bandwidth_probe(0, k_, 1024, 5) * 1e-3) / 1e9
+        for k_, name, bpp in ((0, "copy", 16), (1, "triad", 24), (2, "read", 8))}
+    if not args.no_extras:
+        other = "rb" if args.smoother == "wjacobi" else "wjacobi"
+        okind, oomega = kinds[other]
+        # north_star's target kernel (the red-black fine-grid sweep) when the headline smoother is weighted Jacobi,
+        # and the other way round
+        out["roofline_" + other] = pass_roofline(plan, args, okind, other, oomega, n)
+        # the reference-faithful cycle: V(nu,nu) on the finest level, V(4,4) below it (MGCMTSolver.py:320 does not
+        # forward nu1/nu2; BASELINE.md §4's 208 B/fine point row)
+        plan.fill(0, _lib.SLOT_V, 0, 0.0)
+        steps = max(3, min(args.steps, 10))
+        t = time_cycles(plan, steps, 2, lambda: cycle(nu_coarse=4))
+        out["vcycles_per_s_reference_faithful"] = steps / t
+        out["reference_faithful_cycle"] = {"workload": "V(%d,%d) on the finest level, V(4,4) below (MGCMTSolver.py:320)" % (args.nu, args.nu),
+                                           "ms_per_step": t / steps * 1e3, "value": n * sweeps * steps / t / 1e6, "unit": "MLUPS"}
+        plan.fill(0, _lib.SLOT_V, 0, 0.0)
+        t = time_cycles(plan, steps, 2, lambda: cycle(okind, oomega))
+        out["cycle_" + other] = {"workload": "V(%d,%d) %s on every level" % (args.nu, args.nu, names[other]),
+                                 "ms_per_step": t / steps * 1e3, "vcycles_per_s": steps / t, "value": n * sweeps * steps / t / 1e6, "unit": "MLUPS"}
     # untimed: what the cycles being timed do to the residual: ||f - A v|| / ||f|| after each of
     # ten cycles from a zero start
     plan.fill(0, _lib.SLOT_V, 0, 0.0)
@@ -164,8 +278,29 @@ def main():
         plan.axpy(0, -1.0, F, T)
         history.append(float(np.sqrt(plan.dot(0, T, T)) / f_norm))
     out["residual_reduction_per_cycle"] = history
+    plan.close()
+    if not args.no_extras and g == 16384:
+        # BASELINE config 4's workload (32768^2, V(2,2) red-black) on this ONE GPU: the base of the strong-scaling
+        # curve `bench.py --gpus N` continues.  Right-hand side: the 16384^2 random field interpolated on the device.
+        try:
+            big = Plan(laplacian_operator(2 * g, "2d") * (-1.0 / np.pi ** 2), args.lowest, nvec=1, device=0)
+            big.set_shifts([0.0])
+            big.upload(1, _lib.SLOT_F, 0, f)
+            big.prolong(0, (_lib.SLOT_F, 0), (_lib.SLOT_F, 0))
+            big.fill(0, _lib.SLOT_V, 0, 0.0)
+            steps = 5
+            t = time_cycles(big, steps, 2, lambda: big.vcycle(args.nu, args.nu, _lib.GS_MC, omega=1.0, k=1, nu_coarse=args.nu))
+            out["strong_scaling_base"] = {"workload": "2D Laplacian %d^2 fp64, V(%d,%d) red-black Gauss-Seidel, 1xMI355X (what --gpus N shards)" % (2 * g, args.nu, args.nu),
+                                          "ms_per_step": t / steps * 1e3, "vcycles_per_s": steps / t,
+                                          "value": 4 * n * sweeps * steps / t / 1e6, "unit": "MLUPS"}
+            big.close()
+        except Exception as e:                                  # e.g. a smaller-memory device
+            out["strong_scaling_base"] = {"value": None, "error": str(e)}
+    del f
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.smoother)
+        if not args.no_extras:
+            out["cpu_reference_equivalent"] = cpu_reference_equivalent(128)
     print(json.dumps(out))
 
 

@@ -174,8 +174,29 @@ class UnrecognisedOperator(ValueError):
 _CACHE = {}
 
 
+def _digest(A):
+    """Content digest of a scipy.sparse matrix (O(nnz), the cost of the structural check itself): a matrix mutated in
+    place (``A *= c``, ``A.data[:] = ...``, ``setdiag``) keeps its id, shape and nnz but not this."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    fmt = getattr(A, "format", None)
+    h.update(str(fmt).encode())
+    if fmt in ("csr", "csc", "bsr"):
+        parts = (A.data, A.indices, A.indptr)
+    elif fmt == "coo":
+        parts = (A.data, A.row, A.col)
+    elif fmt == "dia":
+        parts = (A.data, A.offsets)
+    else:                                                    # lil / dok / anything else: go through CSR
+        B = A.tocsr()
+        parts = (B.data, B.indices, B.indptr)
+    for a in parts:
+        h.update(np.ascontiguousarray(a).view(np.uint8).data)
+    return h.digest()
+
+
 def _cache_key(A):
-    return (id(A), A.shape, getattr(A, "nnz", None))
+    return (id(A), A.shape, getattr(A, "nnz", None), _digest(A))
 
 
 def recognise(A, dimension=None):

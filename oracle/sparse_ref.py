@@ -179,6 +179,24 @@ class RefSolver:
             v = (v - omega * (A @ v) / d) + omega * (f / d)
         return v
 
+    def wjacobi_iteration_matrix(self, v0, f, A, nu=4, omega=2. / 3.):
+        """MGCMTSolver.py:193-206 with the reference's COST PROFILE as well as its result: the iteration matrix
+        I - w D^-1 A is materialised by a sparse solve with a sparse right-hand side (N column solves, :195) and
+        applied nu times; the right-hand-side term is solved again in every sweep (:202).  Same values as
+        ``wjacobi`` (tests/test_oracle_golden.py); only bench.py's ``cpu_reference_equivalent`` uses it, to time
+        what the reference's formulation costs on the box's host cores."""
+        import warnings
+        v, f = _col(v0), _col(f)
+        n = v.shape[0]
+        A = sp.csc_matrix(A)
+        D = sp.diags(A.diagonal(), 0, shape=(n, n), format="csc")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            R = sp.eye(n, format="csc") - omega * spsolve(D, A)
+            for _ in range(nu):
+                v = R @ v + omega * np.asarray(spsolve(D, f)).reshape(-1)
+        return v
+
     def gseidel(self, v0, f, A, nu=4):
         """MGCMTSolver.py:210-227 — v <- (D-L)^-1 U v + (D-L)^-1 f: forward lexicographic GS."""
         return self.sor(v0, f, A, nu=nu, omega=1)

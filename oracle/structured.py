@@ -152,7 +152,9 @@ def time_cpu_baseline(smoother, nu, lowest, budget_seconds, grid=8192, workload_
         cycles += 1
     mlups = float(g) * g * 2 * nu * cycles / spent / 1e6
     return {"value": mlups, "unit": "MLUPS", "cores": threads, "kind": "port",
-            "sample": "%d whole V(%d,%d) %s cycles on a %d^2 grid (bounded sample of the %s^2 workload; MLUPS is per point) after "
+            "sample": "%d whole V(%d,%d) %s cycles on a %d^2 grid (%s) after "
                       "1 warm-up cycle, C restatement oracle/mgcmt_oracle.c, OpenMP x%d" %
-                      (cycles, nu, nu, smoother, g, workload_grid or g, threads),
+                      (cycles, nu, nu, smoother, g,
+                       "the full workload" if (workload_grid or g) == g else
+                       "bounded sample of the %s^2 workload; MLUPS is per point" % workload_grid, threads),
             "vcycles_per_s": cycles / spent}

@@ -90,6 +90,21 @@ def test_recognise_reference_operators():
         recognise(sp.random(64, 64, density=0.2, random_state=0) + sp.eye(64), "2d")
 
 
+def test_recognise_sees_in_place_mutation():
+    """A scipy matrix changed in place (same id, shape, nnz) must not come back as the stale cached operator."""
+    sm = MGCMTStencilMaker()
+    A = sp.csr_matrix(sm.laplacian(16))
+    first = recognise(A)
+    assert recognise(A) is first                                   # unchanged matrix: cache hit
+    A *= 2.0
+    second = recognise(A)
+    assert second is not first and np.array_equal(second.diagonal(), A.diagonal())
+    A.data[:] = 0.5 * A.data
+    assert np.array_equal(recognise(A).diagonal(), A.diagonal())
+    A.setdiag(-7.0)
+    assert np.array_equal(recognise(A).diagonal(), A.diagonal())
+
+
 def test_structured_operator_algebra():
     op = laplacian_operator(8, "2d")
     sm = MGCMTStencilMaker()

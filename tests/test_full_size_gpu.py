@@ -1,6 +1,12 @@
-"""GPU-only checks at BASELINE.json's sizes, through size-independent properties (the oracle cannot run
-a 16384^2 cycle in seconds): fused == unfused kernels, linearity of the smoother, and per-cycle residual
-reduction equal to what the C oracle shows at a size it can run."""
+"""GPU-only checks at BASELINE.json's sizes.
+
+Direct parity: one V(2,2) cycle of the HIP path against the C oracle (oracle/mgcmt_oracle.c, the matrix-free
+restatement of MGCMTSolver.py:281-329 pinned by the reference's golden vectors) on the same seeded input at the
+configurations BASELINE.json names — 4096^2 red-black (config 2), 16384^2 weighted Jacobi and red-black (config 3),
+32768^2 red-black on one GPU (config 4's workload), the 8192^2 square-well Hamiltonian (config 5).  The oracle
+runs these on the box's host cores in about 0.2 / 3 / 12 / 1 s per cycle.  Plus size-independent properties: a
+closed-form check (a discrete sine mode is an eigenvector of the Laplacian, so nu Jacobi sweeps scale it by a
+known factor), fused == unfused kernels, linearity of the smoother."""
 import numpy as np
 import pytest
 
@@ -12,6 +18,134 @@ from oracle import structured as st
 
 pytestmark = pytest.mark.gpu
 SCALE = -1 / np.pi ** 2
+
+
+def _oracle_threads():
+    import os
+    st.lib().mgo_set_threads(min(os.cpu_count() or 1, 16))
+
+
+def _one_cycle_vs_oracle(g, kind, omega, nu_coarse=2, seed=11, cycles=1, shift=0.0):
+    """rel_err(HIP, oracle) of `cycles` V(2,2) cycles from a zero start on -laplacian(g)/pi^2 - shift."""
+    _oracle_threads()
+    f = np.random.RandomState(seed).rand(g * g)
+    p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
+    try:
+        p.set_shifts([shift])
+        p.upload(0, _lib.SLOT_F, 0, f)
+        p.fill(0, _lib.SLOT_V, 0, 0.0)
+        for _ in range(cycles):
+            p.vcycle(2, 2, kind, omega=omega, nu_coarse=nu_coarse)
+        got = p.download(0, _lib.SLOT_V, 0)
+    finally:
+        p.close()
+    X, Y = st.laplacian_factors(g, "2d", SCALE)
+    v = np.zeros(g * g)
+    okind = st.WJACOBI if kind == _lib.WJACOBI else st.GS_MC
+    for _ in range(cycles):
+        st.vcycle(X, Y, g, 8, shift, okind, v, f, 2, 2, nu_coarse, omega, inplace=True)
+    del f
+    return rel_err(got, v)
+
+
+def test_config2_4096_redblack_cycle_against_oracle(hip_only):
+    """BASELINE config 2: 4096^2, V(2,2) red-black, two cycles (the second one replays the captured graph), also with
+    the reference's own V(4,4)-below-the-top quirk (MGCMTSolver.py:320) and a shift."""
+    assert _one_cycle_vs_oracle(4096, _lib.GS_MC, 1.0, cycles=2) < 1e-10
+    assert _one_cycle_vs_oracle(4096, _lib.GS_MC, 1.0, nu_coarse=4, shift=0.7) < 1e-10
+    assert _one_cycle_vs_oracle(4096, _lib.WJACOBI, 2. / 3., nu_coarse=4) < 1e-10
+
+
+@pytest.mark.parametrize("kind,omega", [(_lib.WJACOBI, 2. / 3.), (_lib.GS_MC, 1.0)])
+def test_config3_16384_cycle_against_oracle(hip_only, kind, omega):
+    """BASELINE config 3 (the headline workload): one V(2,2) cycle at 16384^2 through every optimised path."""
+    assert _one_cycle_vs_oracle(16384, kind, omega) < 1e-10
+
+
+def test_config4_32768_redblack_cycle_against_oracle(hip_only):
+    """BASELINE config 4's workload on one GPU (the 8-GPU run shards exactly this cycle): 32768^2, V(2,2)
+    red-black.  8 GiB per vector; the oracle needs about 45 GiB of host memory and 10-15 s."""
+    assert _one_cycle_vs_oracle(32768, _lib.GS_MC, 1.0) < 1e-10
+
+
+def test_config5_8192_square_well_against_oracle(hip_only):
+    """BASELINE config 5 at its size: the 8192^2 square-well Hamiltonian (three Kronecker terms: Op5V on the finest
+    level, Op9<3> below).  One V(2,2) cycle of each smoother on the eigen-residual of a random start, and the
+    Rayleigh quotient of one iteration of drivers.potential_well_eigensolve, against the C oracle on the same
+    operator."""
+    import scipy.linalg
+    from multigridcmt_amd.operators import potential_well_operator
+    _oracle_threads()
+    g = 8192
+    op = potential_well_operator(g, 50.0, (g // 4, 3 * g // 4))
+    X = np.ascontiguousarray(np.stack([t[0] for t in op.terms]))
+    Y = np.ascontiguousarray(np.stack([t[1] for t in op.terms]))
+    x = np.random.RandomState(0).random_sample(g * g)
+    x /= np.linalg.norm(x)
+    ax = st.apply(X, Y, 0.0, x)
+    rho = float(np.dot(x, ax))
+    r = ax - rho * x
+    p = Plan(op, 8, nvec=1)
+    try:
+        p.set_shifts([0.0])
+        p.upload(0, _lib.SLOT_W, 0, x)
+        p.apply(0, (_lib.SLOT_W, 0), (_lib.SLOT_T, 0))
+        assert rel_err(p.download(0, _lib.SLOT_T, 0), ax) < 1e-12
+        p.upload(0, _lib.SLOT_F, 0, r)
+        for kind, okind, omega in ((_lib.GS_MC, st.GS_MC, 1.0), (_lib.WJACOBI, st.WJACOBI, 2. / 3.)):
+            p.fill(0, _lib.SLOT_V, 0, 0.0)
+            p.vcycle(2, 2, kind, omega=omega, nu_coarse=2)
+            w = p.download(0, _lib.SLOT_V, 0)
+            w_ref = st.vcycle(X, Y, g, 8, 0.0, okind, np.zeros(g * g), r, 2, 2, 2, omega)
+            assert rel_err(w, w_ref) < 1e-10
+            if kind == _lib.GS_MC:
+                # the Rayleigh-Ritz step of the driver on span{x, w}: rho of the new iterate
+                def ritz(wv):
+                    aw = st.apply(X, Y, 0.0, wv)
+                    A2 = np.array([[rho, np.dot(x, aw)], [np.dot(x, aw), np.dot(wv, aw)]])
+                    M2 = np.array([[1.0, np.dot(x, wv)], [np.dot(x, wv), np.dot(wv, wv)]])
+                    return float(scipy.linalg.eigh(A2, M2)[0][0])
+                want = ritz(w_ref)
+                del w, w_ref
+    finally:
+        p.close()
+    from multigridcmt_amd.drivers import potential_well_eigensolve
+    hist = []
+    potential_well_eigensolve(g, depth=50.0, cycles=1, method="vcycle", nu=2, lowest=8, smoother="rb", seed=0, history=hist)
+    assert abs(hist[0] - want) < 1e-10 * abs(want)
+
+
+def test_config3_16384_sine_mode_closed_form(hip_only):
+    """Independent of every oracle: v_ij = sin(k pi (i+1)/(g+1)) sin(l pi (j+1)/(g+1)) is an eigenvector of the
+    Dirichlet 5-point Laplacian, so with f = 0 nu weighted-Jacobi sweeps multiply it by (1 - omega lambda/d)^nu,
+    lambda/d = sin^2(k pi/(2(g+1))) + sin^2(l pi/(2(g+1))); checked at the headline size for a smooth and an
+    oscillatory mode, through the fused pass and for the operator application itself."""
+    g = 16384
+    i = np.arange(1, g + 1, dtype=np.int64)
+    diag = abs(SCALE) * 4.0 * g * g
+
+    def mode(k):                                          # sin(k pi i / (g+1)) with the argument reduced in integers
+        return np.sin(np.pi * ((k * i) % (2 * (g + 1))) / (g + 1))
+
+    p = Plan(laplacian_operator(g, "2d") * SCALE, g, nvec=1)
+    try:
+        p.set_shifts([0.0])
+        p.fill(0, _lib.SLOT_F, 0, 0.0)
+        for (k, l), nu in (((1, 2), 4), ((g // 2 + 3, g // 3 + 1), 3)):
+            v = np.outer(mode(k), mode(l)).ravel()
+            mu = np.sin(k * np.pi / (2 * (g + 1))) ** 2 + np.sin(l * np.pi / (2 * (g + 1))) ** 2
+            lam = diag * mu                                        # eigenvalue of SCALE * laplacian (SCALE < 0)
+            factor = (1.0 - (2. / 3.) * mu) ** nu                  # D = diag, so omega * lam / D = omega * mu
+            nv = np.linalg.norm(v)
+            p.upload(0, _lib.SLOT_V, 0, v)
+            p.apply(0, (_lib.SLOT_V, 0), (_lib.SLOT_W, 0))
+            # measured against |D| |v|: A v is a difference of terms of that size (for the smooth mode lam / D ~ 1e-7)
+            assert np.linalg.norm(p.download(0, _lib.SLOT_W, 0) - lam * v) / (diag * nv) < 1e-13
+            p.smooth(0, _lib.WJACOBI, nu, 2. / 3., k=1)
+            assert rel_err(p.download(0, _lib.SLOT_V, 0), factor * v) < 1e-12
+            del v
+    finally:
+        p.close()
 
 
 def _residual_norm(p, n):

@@ -230,6 +230,12 @@ def test_rqmin_family(trio):
     A32 = H(sm, 32)
     rq = [X[:, i] @ (A32 @ X[:, i]) / (X[:, i] @ X[:, i]) for i in range(2)]
     assert np.allclose(rq, [0.963017800746613, 1.040538684849706], rtol=1e-9, atol=0)
+    assert np.allclose(rq, gold["rqmg2_nmin4_rq"], rtol=NORTH_STAR, atol=0)
+    # the vectors themselves (the sign of a column is the sign of an eigenvector of the 2x2 pencil, :48 — free)
+    for i in range(2):
+        ref_col = gold["rqmg2_nmin4_X"][:, i]
+        sign = np.sign(np.dot(X[:, i], ref_col))
+        assert rel_err(sign * X[:, i], ref_col) < 1e-8, i
     with pytest.raises(AttributeError):
         solver.rqmin(A, gold["x0"])                                    # M=None crashes in the reference too (:19)
     with pytest.raises(NameError):
