@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MGCMT_ABI_VERSION 1
+#define MGCMT_ABI_VERSION 2
 #define MGCMT_MAX_TERMS 4
 #define MGCMT_HALO_ROWS 8 /* rows of halo kept above and below every level's vectors */
 
@@ -163,17 +163,63 @@ int mgcmt_fused_max_sweeps(const mgcmt_plan* plan, int level, int kind, int* max
 /* how many pre-smoothing sweeps a mode-1 pass with `nsweep` post-smoothing sweeps can recompute on that level */
 int mgcmt_fused_max_recompute(const mgcmt_plan* plan, int level, int kind, int nsweep, int* max_recompute);
 
+/* ---- multi-GPU: row strips with neighbour halo exchange --------------------------------------------
+ * A strip plan (mgcmt_plan_desc.row_begin/row_end/strip_levels) gets a communicator; every exchange below is then
+ * enqueued by the library itself.  mgcmt_comm_init: RCCL (ncclSend/ncclRecv groups and ncclAllGather on HIP streams,
+ * no host synchronisation inside a cycle; librccl is loaded on first use).  Rank 0 obtains the 128-byte id with
+ * mgcmt_comm_unique_id and the host program distributes it (any channel).  mgcmt_comm_init_external: the host
+ * program supplies the transport as callbacks (gloo, MPI, staging through host memory ...); the library synchronises
+ * its stream before each call, `ptr`s are device addresses of this plan, counts are in doubles, a callback returns 0 on
+ * success and must have completed the transfer when it returns. */
+#define MGCMT_UNIQUE_ID_BYTES 128
+typedef struct mgcmt_p2p_op {
+  void* ptr;
+  int64_t count;
+  int32_t peer;
+  int32_t is_send;
+} mgcmt_p2p_op;
+typedef int (*mgcmt_p2p_fn)(void* user, int nops, const mgcmt_p2p_op* ops);                  /* one batch, all at once */
+typedef int (*mgcmt_allgather_fn)(void* user, const void* send, void* recv, int64_t count);  /* recv = nranks * count */
+typedef int (*mgcmt_allreduce_fn)(void* user, double* host_inout, int n);                    /* sum over ranks */
+int mgcmt_comm_unique_id(void* id_out /* MGCMT_UNIQUE_ID_BYTES */);
+int mgcmt_comm_init(mgcmt_plan* plan, int rank, int nranks, const void* unique_id);
+int mgcmt_comm_init_external(mgcmt_plan* plan, int rank, int nranks, mgcmt_p2p_fn p2p, mgcmt_allgather_fn allgather,
+                             mgcmt_allreduce_fn allreduce, void* user);
+int mgcmt_comm_destroy(mgcmt_plan* plan);
+typedef enum mgcmt_comm_option {
+  MGCMT_COMM_OPT_OVERLAP = 0, /* default 1 (RCCL): the exchange of a pass's boundary rows runs on a second stream beside
+                                 the launch that produces the interior rows */
+  MGCMT_COMM_OPT_SPLIT = 1,   /* default 1: boundary rows are produced by their own launches first */
+  MGCMT_COMM_OPT_SELF_RING = 2 /* default 0; 1 on a ONE-rank communicator: the rank acts as its own upper and lower neighbour in
+                                 every exchange of a cycle (the rows it receives are never read): the split launches, the
+                                 transport and the stream overlap run for real on one GPU */
+} mgcmt_comm_option;
+int mgcmt_comm_set_option(mgcmt_plan* plan, int option, int value);
+/* halo rows of vector 0 of the slots in slot_mask (bit s = slot s) on strip level `level` <- the chain neighbours'
+ * boundary rows, one batch.  Adding 0x100 on a ONE-rank communicator treats the strip as a ring (it is its own upper
+ * and lower neighbour): a self-test of the transport. */
+int mgcmt_halo_exchange(mgcmt_plan* plan, int level, int slot_mask, void* stream);
+/* strips of (level, slot) of all ranks -> the whole-grid finest level of `coarse` (dst_slot) on every rank */
+int mgcmt_gather_coarse(mgcmt_plan* plan, int level, int slot, mgcmt_plan* coarse, int dst_slot, void* stream);
+/* host_inout[0..n) <- sum over ranks (norms, inner products: the np.dot / np.linalg.norm call sites); synchronises */
+int mgcmt_allreduce_sum(mgcmt_plan* plan, double* host_inout, int n, void* stream);
+/* one V(nu1,nu2) cycle (MGCMTSolver.py:281-329) of the sharded hierarchy: `plan` holds the finest levels as row strips,
+ * `coarse` the first whole-grid level and everything below it on every rank.  flags: the caller vouches that the halo
+ * rows of the fine level's V (nothing but mgcmt_sharded_vcycle wrote V since the previous cycle) / F (since the
+ * previous cycle with the same right-hand side) are still the neighbours' rows, which saves their exchange. */
+#define MGCMT_SHARDED_V_HALO_VALID 1
+#define MGCMT_SHARDED_F_HALO_VALID 2
+int mgcmt_sharded_vcycle(mgcmt_plan* plan, mgcmt_plan* coarse, int nu1, int nu2, int nu_coarse, int kind, double omega,
+                         int flags, void* stream);
+
 /* plan options: MGCMT_OPT_FUSED (default 1) selects the fused row-streaming kernels on large constant-
  * coefficient levels; 0 forces the one-launch-per-operation kernels everywhere (A/B checks) */
 typedef enum mgcmt_option {
   MGCMT_OPT_FUSED = 0,
-  MGCMT_OPT_FUSED_ROWS = 1, /* tuning: rows per wave chunk, 0 = auto */
+  MGCMT_OPT_FUSED_ROWS = 1, /* tuning: rows per wave chunk of this plan's fused passes, 0 = auto */
   MGCMT_OPT_RECOMPUTE = 3,  /* default 1: on levels of >= 2^22 points down-leg passes do not store the pre-smoothed iterate and
                                up-leg passes recompute it; 2: on every fused level; 0: never */
   MGCMT_OPT_GRAPH = 2,      /* default 1: mgcmt_vcycle replays its launch sequence as a HIP graph from the second call on */
-  MGCMT_OPT_WIDE = 5,       /* default 0 (measured slower so far); 1: weighted-Jacobi passes on 5-point levels of >= 2048 columns use
-                               256-column windows (two 128-column halves per wave: half the overlap reads); 2: from 256 columns on
-                               (tests).  Process-wide. */
   MGCMT_OPT_TAIL = 4        /* default 1: the 2-D levels of at most 32 x 32 points below a cycle's top level, coarse solve
                                included, run as ONE launch out of LDS (needs MGCMT_OPT_FUSED; not with Gram-Schmidt) */
 } mgcmt_option;

@@ -18,11 +18,10 @@ OP_A, OP_M = 0, 1
 HALO_ROWS = 8
 MAX_TERMS = 4
 MAX_VEC = 32
-ABI_VERSION = 1
+ABI_VERSION = 2
 OPT_FUSED = 0
 OPT_FUSED_ROWS = 1
 OPT_TAIL = 4
-OPT_WIDE = 5
 OPT_GRAPH = 2
 OPT_RECOMPUTE = 3
 
@@ -42,6 +41,20 @@ class PlanDesc(ctypes.Structure):
 
 
 _dp = POINTER(c_double)
+
+
+class P2POp(ctypes.Structure):
+    _fields_ = [("ptr", c_void_p), ("count", c_int64), ("peer", c_int32), ("is_send", c_int32)]
+
+
+P2P_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, POINTER(P2POp))
+ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_int64)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, _dp, c_int)
+UNIQUE_ID_BYTES = 128
+COMM_OPT_OVERLAP, COMM_OPT_SPLIT, COMM_OPT_SELF_RING = 0, 1, 2
+SHARDED_V_HALO_VALID, SHARDED_F_HALO_VALID = 1, 2
+HALO_RING = 0x100
+
 _SIGNATURES = {
     "mgcmt_last_error": (c_char_p, []),
     "mgcmt_abi_version": (c_int, []),
@@ -79,6 +92,15 @@ _SIGNATURES = {
     "mgcmt_fused_pass": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p]),
     "mgcmt_fused_max_sweeps": (c_int, [c_void_p, c_int, c_int, POINTER(c_int)]),
     "mgcmt_fused_max_recompute": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int)]),
+    "mgcmt_comm_unique_id": (c_int, [c_void_p]),
+    "mgcmt_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "mgcmt_comm_init_external": (c_int, [c_void_p, c_int, c_int, P2P_FN, ALLGATHER_FN, ALLREDUCE_FN, c_void_p]),
+    "mgcmt_comm_destroy": (c_int, [c_void_p]),
+    "mgcmt_comm_set_option": (c_int, [c_void_p, c_int, c_int]),
+    "mgcmt_halo_exchange": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "mgcmt_gather_coarse": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mgcmt_allreduce_sum": (c_int, [c_void_p, _dp, c_int, c_void_p]),
+    "mgcmt_sharded_vcycle": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p]),
     "mgcmt_plan_set_option": (c_int, [c_void_p, c_int, c_int]),
     "mgcmt_bandwidth_probe": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _dp, c_void_p]),
     "mgcmt_time_smoother": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, _dp, c_void_p]),

@@ -28,9 +28,6 @@ namespace mgcmt {
 
 namespace fused {
 
-#ifndef MGCMT_FUSED_ROWS
-#define MGCMT_FUSED_ROWS 0
-#endif
 #ifndef MGCMT_FUSED_DEPTH
 #define MGCMT_FUSED_DEPTH 3
 #endif
@@ -64,6 +61,8 @@ struct FusedArgs {
   double omega;
   int n_row_chunks, n_col_groups;
   int rows_per_chunk;  // rows a wave marches over (even), plus the overlap
+  int out_lo, out_hi;  // local rows this launch produces (even bounds; 0 .. nr for a whole pass)
+  int rows_override;   // tuning: rows per chunk, 0 = automatic (host side only)
 };
 
 #ifndef MGCMT_FUSED_NT_STORE
@@ -458,7 +457,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   (void)lane_up;  // (only the ds_bpermute form of the lane reads takes the addresses)
   (void)lane_dn;
   const int strip = group * kWavesPerBlock + wave;
-  const int nc = (int)a.nc, nr = (int)a.nr, cnc = (int)a.cnc;
+  const int nc = (int)a.nc, cnc = (int)a.cnc;
   const int row_lo = (int)a.row_lo, row_hi = (int)a.row_hi;
   if (strip * WOUT >= nc) return;  // wave-uniform
   const int q = blockIdx.y;
@@ -478,8 +477,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   const double* __restrict__ ec = PROLONG ? a.ec + q * a.cstride : nullptr;
   double* __restrict__ rc = RESTRICT ? a.rc + q * a.cstride : nullptr;
 
-  const int r_begin = chunk * a.rows_per_chunk;
-  const int r_end = r_begin + a.rows_per_chunk < nr ? r_begin + a.rows_per_chunk : nr;
+  const int r_begin = a.out_lo + chunk * a.rows_per_chunk;
+  const int r_end = r_begin + a.rows_per_chunk < a.out_hi ? r_begin + a.rows_per_chunk : a.out_hi;
   const int rstart = r_begin - (S + E);
   const int rstop = r_end + S + XL + 2 * E;  // rows [rstart, rstop) are marched over
 
@@ -895,7 +894,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
 #define MGCMT_FUSED_MIN_ROWS 4
 #endif
 constexpr long kFusedMinRows = MGCMT_FUSED_MIN_ROWS;  // shortest chunk: a wave's march has a fixed cost per row step
-long fused_rows_override();                            // tuning knob (kernels_fused.hip), 0 = automatic
 
 template <class OP, int KIND, int NSWEEP, int FLAGS>
 void launch_one(hipStream_t s, FusedArgs a, int k) {
@@ -919,17 +917,19 @@ void launch_one(hipStream_t s, FusedArgs a, int k) {
     else
       resident_blocks = per_cu * prop.multiProcessorCount;
   }
-  long rows = fused_rows_override();
+  const long nrows = a.out_hi - a.out_lo;  // rows this launch produces
+  if (nrows <= 0) return;
+  long rows = a.rows_override;
   if (rows <= 0) {
     long chunks = (long)(0.9 * resident_blocks) / (groups * k);
     if (chunks < 1) chunks = 1;
-    rows = (a.nr + chunks - 1) / chunks;
+    rows = (nrows + chunks - 1) / chunks;
     if (rows < kFusedMinRows) rows = kFusedMinRows;
   }
-  if (rows > a.nr) rows = a.nr;
+  if (rows > nrows) rows = nrows;
   rows = (rows + 1) & ~1L;
   a.rows_per_chunk = (int)rows;
-  a.n_row_chunks = (int)((a.nr + rows - 1) / rows);
+  a.n_row_chunks = (int)((nrows + rows - 1) / rows);
   const unsigned blocks = (unsigned)(groups8 * a.n_row_chunks);
   hipLaunchKernelGGL((k_fused<OP, KIND, NSWEEP, FLAGS>), dim3(blocks, (unsigned)k), dim3(64 * kWavesPerBlock), 0, s, a);
 }
@@ -974,6 +974,5 @@ void launch_fused_op9c(hipStream_t s, const fused::FusedArgs& a, int multicolour
 void launch_fused_op9(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);    // two terms
 void launch_fused_op9m3(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);  // three terms
 void launch_fused_op5v(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);   // 5-point + product potential
-bool launch_fused_wide(hipStream_t s, const fused::FusedArgs& a, int nsweep, int flags, int k);  // 5-point Jacobi, 256-column windows
 
 }  // namespace mgcmt

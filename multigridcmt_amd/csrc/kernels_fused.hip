@@ -4,28 +4,6 @@
 
 namespace mgcmt {
 
-namespace {
-#ifndef MGCMT_FUSED_ROWS
-#define MGCMT_FUSED_ROWS 0
-#endif
-long g_fused_rows_override = MGCMT_FUSED_ROWS;  // 0 = automatic
-}  // namespace
-
-namespace fused {
-long fused_rows_override() { return g_fused_rows_override; }
-}  // namespace fused
-
-void fused_set_rows(long rows) { g_fused_rows_override = rows; }
-
-namespace {
-// 0 (default): never — measured 4 % SLOWER than the 128-column kernels at 16384^2 (plain pass 1.245 vs 1.192 ms): the
-// halved overlap reads do not make up for half as many waves per SIMD.  1: on levels of at least kWideMinCols columns,
-// 2: wherever a window fits (tests).  Kept as an A/B switch for further tuning.
-int g_fused_wide = 0;
-}
-void fused_set_wide(int mode) { g_fused_wide = mode; }
-constexpr long kWideMinCols = 2048;
-
 #ifndef MGCMT_FUSED_MIN_COLS
 #define MGCMT_FUSED_MIN_COLS 16
 #endif
@@ -56,8 +34,12 @@ int fused_max_recompute(const KOp& op, int multicolour, int nsweep) {
 // correction), 2 residual+restriction last (coarse = the coarse right-hand side); mode & 4: vin is zero;
 // mode & 8: vout is not written (mode 2 only); npre: pre-smoothing sweeps recomputed before the correction (mode 1).
 void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
-                  double omega, int multicolour, int nsweep, int mode, int npre, long row_lo, long row_hi, long last_row, int k) {
+                  double omega, int multicolour, int nsweep, int mode, int npre, long row_lo, long row_hi, long last_row, int k,
+                  long rows_override, long out_lo, long out_hi) {
   fused::FusedArgs a{};
+  a.rows_override = (int)rows_override;
+  a.out_lo = (int)out_lo;
+  a.out_hi = (int)(out_hi < 0 ? g.nr : out_hi);
   a.vin = vin.p;
   a.f = f.p;
   a.vout = vout.p;
@@ -83,9 +65,7 @@ void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, K
   a.omega = omega;
   const int flags = (mode & 15) | (npre << fused::kPreShift);
   if (op.five_point) {
-    // the passes that move the most bytes: 256-column windows halve the reads lost to the window overlap
-    const bool wide = !multicolour && g_fused_wide != 0 && (g.nc & 3) == 0 && g.nc >= (g_fused_wide == 2 ? 256 : kWideMinCols);
-    if (!(wide && launch_fused_wide(s, a, nsweep, flags, k))) launch_fused_op5(s, a, multicolour, nsweep, flags, k);
+    launch_fused_op5(s, a, multicolour, nsweep, flags, k);
   } else if (op.five_diag) {
     for (int m = 0; m < op.ndiag; ++m) {
       a.X[m] = op.dX[m];

@@ -68,10 +68,12 @@ void launch_lex_sweep(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doub
 bool fused_supported(const KGrid& g, const KOp& op);
 int fused_max_sweeps(const KOp& op, int multicolour, bool strip);
 int fused_max_recompute(const KOp& op, int multicolour, int nsweep);
-void fused_set_rows(long rows);
-void fused_set_wide(int mode);  // tuning: rows per chunk, 0 = automatic
+// rows_override: rows per wave chunk (0 = automatic); [out_lo, out_hi): the local rows this launch produces (even
+// bounds; the whole strip is 0 .. g.nr) — a sharded pass runs its boundary rows first so that their exchange overlaps
+// the interior launch
 void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
-                  double omega, int multicolour, int nsweep, int mode, int npre, long row_lo, long row_hi, long last_row, int k);
+                  double omega, int multicolour, int nsweep, int mode, int npre, long row_lo, long row_hi, long last_row, int k,
+                  long rows_override = 0, long out_lo = 0, long out_hi = -1);
 
 // vector algebra; scalar results / inputs live in device memory so nothing syncs with the host
 void launch_fill(hipStream_t s, double* p, long n, double value);

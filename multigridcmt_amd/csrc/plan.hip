@@ -7,48 +7,24 @@
 #include <string>
 #include <vector>
 
-#include "mgcmt_internal.h"
+#include "plan_internal.h"
 
 using namespace mgcmt;
 
 namespace {
-
 thread_local std::string g_last_error;
+}
 
+namespace mgcmt {
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+}  // namespace mgcmt
 
-#define MG_HIP(expr)                                                                                    \
-  do {                                                                                                  \
-    hipError_t e_ = (expr);                                                                             \
-    if (e_ != hipSuccess)                                                                               \
-      return fail(MGCMT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
-  } while (0)
-
-#define MG_TRY(expr)          \
-  do {                        \
-    int rc_ = (expr);         \
-    if (rc_ != MGCMT_OK) return rc_; \
-  } while (0)
+namespace {
 
 bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
-
-// tridiagonal factor on the host: lo, di, up concatenated, length 3n
-struct Tri {
-  int64_t n = 0;
-  std::vector<double> a;
-  double lo(int64_t i) const { return a[i]; }
-  double di(int64_t i) const { return a[n + i]; }
-  double up(int64_t i) const { return a[2 * n + i]; }
-  double at(int64_t r, int64_t c) const {
-    if (c == r - 1) return lo(r);
-    if (c == r) return di(r);
-    if (c == r + 1) return up(r);
-    return 0.0;
-  }
-};
 
 // Galerkin product of one factor: R1 * T * P1 with R1 = full weighting (1/4,1/2,1/4 on fine
 // 2I..2I+2) and P1 = 2 R1^T (MGCMTStencilMaker.py:27-78, MGCMTSolver.py:318).  Stays tridiagonal.
@@ -87,85 +63,6 @@ Tri identity_tri(int64_t n) {
   for (int64_t i = 0; i < n; ++i) t.a[n + i] = 1.0;
   return t;
 }
-
-struct HostOp {
-  int nterms = 0;
-  std::vector<Tri> X, Y;  // per term
-};
-
-struct DevOp {
-  KOp k{};
-  std::vector<double*> owned;
-};
-
-struct BandState {
-  KBand b{};
-  double* inv = nullptr;  // explicit inverse per vector when the coarsest level has at most 1024 unknowns
-  bool valid = false;
-  int k = 0;
-  std::vector<double> shifts;
-};
-
-struct Level {
-  int64_t gr = 1, gc = 1;  // global rows / cols
-  int64_t r0 = 0, nr = 1;  // local strip
-  int64_t stride = 0;      // elements between vectors (halo rows included)
-  double* base[4] = {nullptr, nullptr, nullptr, nullptr};  // allocation start per slot
-  HostOp hA, hM;
-  DevOp dA, dM;
-  BandState band;
-  KGrid grid() const { return KGrid{(long)nr, (long)gc, 0}; }
-};
-
-}  // namespace
-
-struct mgcmt_plan {
-  int dim = 1;
-  int nvec = 1;
-  int device = 0;
-  int64_t g = 0, lowest = 0;
-  std::vector<Level> levels;
-  double* d_shifts = nullptr;   // [kMaxVec] current shifts
-  double* d_zero = nullptr;     // [kMaxVec] zeros (apply without shift)
-  double* d_partials = nullptr; // reduction scratch
-  double* d_scalars = nullptr;  // [4*kMaxVec] reduction results
-  std::vector<double> h_shifts;
-  bool has_mass = false;
-  bool use_fused = true;
-  bool use_tail = true;   // levels of at most 32 x 32 points as one launch (kernels_tail.hip)
-  bool use_recompute = true;  // down-leg passes skip storing V', up-leg passes recompute it (fused_kernel.h)
-  bool force_recompute = false;  // ... on every fused level, not only the bandwidth-bound ones (tests)
-  // HIP-graph replay of whole cycles (mgcmt_vcycle): the launch sequence of a cycle is fixed by its
-  // parameters and by which of the two buffers of every level currently is "V", so it is captured once per
-  // such state and replayed; small grids are launch-latency-bound otherwise.
-  bool use_graph = true;
-  hipStream_t capture_stream = nullptr;
-  struct CycleGraph {
-    hipGraphExec_t exec = nullptr;
-    std::vector<double*> post_state;  // base pointers of slots V and T of every level after the cycle
-  };
-  std::map<std::string, CycleGraph> graphs;
-  std::map<std::string, int> cycle_seen;
-  void graphs_invalidate() {  // a captured launch sequence is only valid for the options it was captured under
-    for (auto& g : graphs)
-      if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
-    graphs.clear();
-    cycle_seen.clear();
-  }
-
-  KGrid kgrid(int l) const {
-    KGrid kg = levels[l].grid();
-    kg.coarsen_rows = dim == 2 ? 1 : 0;
-    return kg;
-  }
-  KVec kvec(int l, int slot, int vec = 0) const {
-    const Level& L = levels[l];
-    return KVec{L.base[slot] + (long)kHalo * L.gc + (long)vec * L.stride, (long)L.stride};
-  }
-  long interior(int l) const { return (long)levels[l].nr * levels[l].gc; }
-};
-
-namespace {
 
 int upload_op(const HostOp& h, const Level& L, int dim, DevOp* d) {
   KOp& k = d->k;
@@ -297,6 +194,8 @@ int upload_op(const HostOp& h, const Level& L, int dim, DevOp* d) {
   return MGCMT_OK;
 }
 
+}  // namespace
+namespace mgcmt {
 int ensure_slot(mgcmt_plan* p, int l, int slot) {
   Level& L = p->levels[l];
   if (L.base[slot]) return MGCMT_OK;
@@ -306,6 +205,9 @@ int ensure_slot(mgcmt_plan* p, int l, int slot) {
   MG_HIP(hipMemset(L.base[slot], 0, bytes));
   return MGCMT_OK;
 }
+
+}  // namespace mgcmt
+namespace {
 
 int check_level(const mgcmt_plan* p, int l) {
   if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
@@ -327,16 +229,24 @@ int check_k(const mgcmt_plan* p, int k) {
 
 hipStream_t S(void* s) { return (hipStream_t)s; }
 
+}  // namespace
+namespace mgcmt {
 int post_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MGCMT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return MGCMT_OK;
 }
 
+}  // namespace mgcmt
+namespace {
+
 // ---- smoothers --------------------------------------------------------------------------------
 
-// one fused row-streaming pass V -> T (then swapped) on a constant 5-point level
-int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, hipStream_t s, int npre = 0) {
+}  // namespace
+namespace mgcmt {
+// one fused pass V -> T (then swapped) on a level the fused kernels cover
+int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, hipStream_t s, int npre, long out_lo,
+               long out_hi, bool swap) {
   Level& L = p->levels[l];
   KVec coarse{nullptr, 0};
   long cnc = 0;
@@ -347,8 +257,9 @@ int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mod
   const long row_lo = L.r0 == 0 ? 0 : -kHalo;
   const long row_hi = L.r0 + L.nr == L.gr ? L.nr : L.nr + kHalo;
   launch_fused(s, p->kgrid(l), L.dA.k, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_T), coarse, cnc,
-               p->d_shifts, omega, kind == MGCMT_GS_MC ? 1 : 0, nsweep, mode, npre, row_lo, row_hi, L.gr - 1 - L.r0, k);
-  if (!(mode & 8)) std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);  // a no-store pass leaves V as it was
+               p->d_shifts, omega, kind == MGCMT_GS_MC ? 1 : 0, nsweep, mode, npre, row_lo, row_hi, L.gr - 1 - L.r0, k, p->fused_rows,
+               out_lo, out_hi);
+  if (swap && !(mode & 8)) std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);  // a no-store pass leaves V as it was
   return MGCMT_OK;
 }
 
@@ -360,6 +271,8 @@ int pass_sweeps(const mgcmt_plan* p, int l, int kind, int left) {
   const int cap = fused_max_sweeps(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0, p->levels[l].nr != p->levels[l].gr);
   return left < cap ? left : cap;
 }
+}  // namespace mgcmt
+namespace {
 
 int smooth_impl(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hipStream_t s) {
   Level& L = p->levels[l];
@@ -810,6 +723,7 @@ int mgcmt_plan_create(const mgcmt_plan_desc* d, mgcmt_plan** out) {
 
 int mgcmt_plan_destroy(mgcmt_plan* p) {
   if (!p) return MGCMT_OK;
+  comm_release(p);
   for (Level& L : p->levels) {
     for (int s = 0; s < 4; ++s)
       if (L.base[s]) (void)hipFree(L.base[s]);
@@ -1197,18 +1111,13 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
     p->use_graph = value != 0;
     return MGCMT_OK;
   }
-  if (option == MGCMT_OPT_WIDE) {
-    fused_set_wide(value);  // process-wide, like the rows knob
-    p->graphs_invalidate();
-    return MGCMT_OK;
-  }
   if (option == MGCMT_OPT_TAIL) {
     p->use_tail = value != 0;
     p->graphs_invalidate();
     return MGCMT_OK;
   }
   if (option == MGCMT_OPT_FUSED_ROWS) {
-    fused_set_rows(value);  // process-wide tuning knob: captured graphs of OTHER plans keep their launch geometry
+    p->fused_rows = value;
     p->graphs_invalidate();
     return MGCMT_OK;
   }

@@ -1,0 +1,493 @@
+// Sharded V-cycle: communicator and cycle driver of a row-strip plan (north_star: "the finest grid
+// levels domain-decompose across the 8 GPUs of one node with RCCL neighbour halo exchange over xGMI, coarser levels
+// agglomerating").  Host code only.
+//
+// Transport 1 — RCCL, used directly from this library (no Python on the data path): one communicator per strip plan,
+// ncclSend/ncclRecv pairs in one group per exchange and one ncclAllGather per cycle, enqueued on HIP streams with no
+// host synchronisation anywhere in a cycle.  librccl is loaded with dlopen at mgcmt_comm_init, so single-GPU users
+// of libmgcmt_hip.so do not need it; the handful of declarations below restate rccl.h (ROCm 7.2:
+// /opt/rocm/include/rccl/rccl.h:40-43,187,220,260,339,448,467,611,678,700,722,923,933).
+// Transport 2 — callbacks supplied by the host program (gloo / MPI / anything): the library synchronises its stream
+// and hands over device pointers.  The CPU rehearsal of the N > 1 path (tests/test_distributed.py, gloo) and ranks
+// sharing one GPU go through it, so the cycle below is the ONE implementation of the schedule.
+//
+// Overlap: the boundary rows of a strip are produced by their own small launches FIRST; their exchange then runs on
+// a second stream beside the launch that produces the interior rows, and the next pass waits for both.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "plan_internal.h"
+
+using namespace mgcmt;
+
+namespace {
+
+// ---- the slice of the RCCL API this file uses ---------------------------------------------------------------
+struct RcclUniqueId {
+  char internal[MGCMT_UNIQUE_ID_BYTES];
+};
+typedef void* RcclComm;
+constexpr int kRcclSuccess = 0, kRcclSum = 0, kRcclFloat64 = 8;
+
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+  int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(RcclComm) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+  std::string error;
+};
+
+RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.handle ? &api : nullptr;
+  tried = true;
+  // a librccl already in the process (e.g. PyTorch's own copy, same SONAME) is reused by the first name
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (api.handle) break;
+  }
+  if (!api.handle) {
+    api.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+    return nullptr;
+  }
+  bool ok = true;
+  auto sym = [&](const char* name) {
+    void* f = dlsym(api.handle, name);
+    if (!f) {
+      ok = false;
+      api.error = std::string("librccl lacks ") + name;
+    }
+    return f;
+  };
+  api.GetUniqueId = (int (*)(RcclUniqueId*))sym("ncclGetUniqueId");
+  api.CommInitRank = (int (*)(RcclComm*, int, RcclUniqueId, int))sym("ncclCommInitRank");
+  api.CommDestroy = (int (*)(RcclComm))sym("ncclCommDestroy");
+  api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+  api.GroupStart = (int (*)())sym("ncclGroupStart");
+  api.GroupEnd = (int (*)())sym("ncclGroupEnd");
+  api.Send = (int (*)(const void*, size_t, int, int, RcclComm, hipStream_t))sym("ncclSend");
+  api.Recv = (int (*)(void*, size_t, int, int, RcclComm, hipStream_t))sym("ncclRecv");
+  api.AllGather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))sym("ncclAllGather");
+  api.AllReduce = (int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t))sym("ncclAllReduce");
+  if (!ok) {
+    dlclose(api.handle);
+    api.handle = nullptr;
+    return nullptr;
+  }
+  return &api;
+}
+
+#define MG_RCCL(api, expr)                                                                         \
+  do {                                                                                             \
+    int r_ = (expr);                                                                               \
+    if (r_ != kRcclSuccess)                                                                        \
+      return fail(MGCMT_ERR_HIP, std::string(#expr) + ": " + ((api)->GetErrorString ? (api)->GetErrorString(r_) : "rccl error")); \
+  } while (0)
+
+}  // namespace
+
+namespace mgcmt {
+
+struct ShardComm {
+  int rank = 0, nranks = 1;
+  RcclComm nccl = nullptr;  // transport 1
+  mgcmt_p2p_fn p2p = nullptr;  // transport 2
+  mgcmt_allgather_fn allgather = nullptr;
+  mgcmt_allreduce_fn allreduce = nullptr;
+  void* user = nullptr;
+  hipStream_t comm_stream = nullptr;  // exchanges of boundary rows run here, beside the interior launch
+  hipEvent_t ev_boundary = nullptr, ev_done = nullptr;
+  bool pending = false;   // an exchange is in flight on comm_stream: the next pass waits for ev_done
+  bool overlap = true;    // RCCL transport only
+  bool split = true;      // boundary rows first (both transports)
+  bool self_ring = false; // one-rank self-test: the rank is its own neighbour above and below in every exchange
+  double* d_red = nullptr;
+};
+
+void comm_release(mgcmt_plan* p) {
+  if (!p || !p->comm) return;
+  ShardComm* c = p->comm;
+  if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  if (c->ev_boundary) (void)hipEventDestroy(c->ev_boundary);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->d_red) (void)hipFree(c->d_red);
+  delete c;
+  p->comm = nullptr;
+}
+
+}  // namespace mgcmt
+
+namespace {
+
+constexpr int kRing = 0x100;       // mgcmt_halo_exchange: treat a ONE-rank chain as a ring (transport self-test)
+constexpr long kBoundaryRows = 2 * kHalo;  // rows of a strip's edge produced first: the neighbour's halo rows of V and,
+                                           // restricted, of the coarse right-hand side
+
+struct Msg {
+  double* ptr;
+  size_t count;
+  int peer;
+  bool send;
+};
+
+int check_comm(const mgcmt_plan* p) {
+  if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
+  if (!p->comm) return fail(MGCMT_ERR_INVALID, "plan has no communicator (mgcmt_comm_init / mgcmt_comm_init_external)");
+  return MGCMT_OK;
+}
+
+// boundary rows out / halo rows in of vector 0 of (level, slot) for the chain neighbours
+int halo_msgs(mgcmt_plan* p, int l, int slot, bool ring, std::vector<Msg>* out) {
+  const ShardComm* c = p->comm;
+  MG_TRY(ensure_slot(p, l, slot));
+  const Level& L = p->levels[l];
+  if (L.nr == L.gr && !ring) return MGCMT_OK;  // not a strip level: nothing to exchange
+  if (L.nr < kHalo) return fail(MGCMT_ERR_INVALID, "strip has fewer rows than the halo");
+  const size_t cnt = (size_t)kHalo * L.gc;
+  double* v = p->kvec(l, slot).p;
+  double* top = v;
+  double* bottom = v + (long)(L.nr - kHalo) * L.gc;
+  double* halo_up = v - (long)kHalo * L.gc;
+  double* halo_dn = v + (long)L.nr * L.gc;
+  if (ring) {  // one rank, itself above and below: messages to one peer match in order
+    out->push_back({bottom, cnt, 0, true});
+    out->push_back({top, cnt, 0, true});
+    out->push_back({halo_up, cnt, 0, false});
+    out->push_back({halo_dn, cnt, 0, false});
+    return MGCMT_OK;
+  }
+  const int up = c->rank - 1, down = c->rank + 1;
+  if (up >= 0) {
+    out->push_back({top, cnt, up, true});
+    out->push_back({halo_up, cnt, up, false});
+  }
+  if (down < c->nranks) {
+    out->push_back({bottom, cnt, down, true});
+    out->push_back({halo_dn, cnt, down, false});
+  }
+  return MGCMT_OK;
+}
+
+int run_msgs(mgcmt_plan* p, const std::vector<Msg>& msgs, hipStream_t s) {
+  ShardComm* c = p->comm;
+  if (msgs.empty()) return MGCMT_OK;
+  if (c->nccl) {
+    RcclApi* api = rccl();
+    MG_RCCL(api, api->GroupStart());
+    for (const Msg& m : msgs) {
+      if (m.send) MG_RCCL(api, api->Send(m.ptr, m.count, kRcclFloat64, m.peer, c->nccl, s));
+      else MG_RCCL(api, api->Recv(m.ptr, m.count, kRcclFloat64, m.peer, c->nccl, s));
+    }
+    MG_RCCL(api, api->GroupEnd());
+    return MGCMT_OK;
+  }
+  if (!c->p2p) return fail(MGCMT_ERR_INVALID, "communicator has no point-to-point transport");
+  std::vector<mgcmt_p2p_op> ops(msgs.size());
+  for (size_t i = 0; i < msgs.size(); ++i) ops[i] = mgcmt_p2p_op{msgs[i].ptr, (int64_t)msgs[i].count, msgs[i].peer, msgs[i].send ? 1 : 0};
+  MG_HIP(hipStreamSynchronize(s));  // the callback moves the bytes itself: they must be there
+  if (c->p2p(c->user, (int)ops.size(), ops.data()) != 0) return fail(MGCMT_ERR_HIP, "external point-to-point transport failed");
+  return MGCMT_OK;
+}
+
+// the main stream waits for an exchange still running beside it
+int join_exchange(mgcmt_plan* p, hipStream_t s) {
+  ShardComm* c = p->comm;
+  if (c->pending) {
+    MG_HIP(hipStreamWaitEvent(s, c->ev_done, 0));
+    c->pending = false;
+  }
+  return MGCMT_OK;
+}
+
+// One fused pass on strip level l whose products the neighbours need next: V' boundary rows (unless the pass stores
+// nothing) and, after a restriction, the coarse right-hand side's boundary rows (when level l+1 is a strip level too).
+// Boundary rows first, their exchange beside the interior rows.
+int strip_pass(mgcmt_plan* p, int l, int kind, int n, double omega, int mode, int npre, hipStream_t s, bool coarse_is_strip) {
+  ShardComm* c = p->comm;
+  Level& L = p->levels[l];
+  MG_TRY(join_exchange(p, s));
+  const bool stores_v = !(mode & 8);
+  const bool sends_f = (mode & 3) == 2 && coarse_is_strip;
+  const bool ring = c->self_ring;
+  const bool up = c->rank > 0 || ring, down = c->rank + 1 < c->nranks || ring;
+  const long B = kBoundaryRows;
+  const bool split = c->split && (stores_v || sends_f) && (up || down) && L.nr >= 4 * B;
+  std::vector<Msg> msgs;
+  if (!split) {
+    MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre));
+    if (stores_v) MG_TRY(halo_msgs(p, l, MGCMT_SLOT_V, ring, &msgs));
+    if (sends_f) MG_TRY(halo_msgs(p, l + 1, MGCMT_SLOT_F, ring, &msgs));
+    return run_msgs(p, msgs, s);
+  }
+  const long lo = up ? B : 0, hi = down ? L.nr - B : L.nr;
+  if (up) MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre, 0, B, false));
+  if (down) MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre, L.nr - B, L.nr, false));
+  // the messages name the buffer the pass writes: V' lives in slot T until the roles are swapped below
+  if (stores_v) {
+    std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
+    const int rc = halo_msgs(p, l, MGCMT_SLOT_V, ring, &msgs);
+    std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
+    MG_TRY(rc);
+  }
+  if (sends_f) MG_TRY(halo_msgs(p, l + 1, MGCMT_SLOT_F, ring, &msgs));
+  if (c->nccl && c->overlap) {
+    MG_HIP(hipEventRecord(c->ev_boundary, s));
+    MG_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
+    MG_TRY(run_msgs(p, msgs, c->comm_stream));
+    MG_HIP(hipEventRecord(c->ev_done, c->comm_stream));
+    c->pending = true;
+    MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre, lo, hi, true));
+    return MGCMT_OK;
+  }
+  MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre, lo, hi, true));
+  return run_msgs(p, msgs, s);
+}
+
+std::vector<int> split_sweeps(const mgcmt_plan* p, int l, int kind, int nu) {
+  std::vector<int> out;
+  for (int left = nu; left > 0;) {
+    const int n = pass_sweeps(p, l, kind, left);
+    out.push_back(n);
+    left -= n;
+  }
+  return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mgcmt_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(MGCMT_ERR_INVALID, "null output");
+  RcclApi* api = rccl();
+  if (!api) return fail(MGCMT_ERR_UNSUPPORTED, "RCCL is not available in this process");
+  RcclUniqueId id;
+  MG_RCCL(api, api->GetUniqueId(&id));
+  memcpy(id_out, id.internal, MGCMT_UNIQUE_ID_BYTES);
+  return MGCMT_OK;
+}
+
+static int comm_common(mgcmt_plan* p, int rank, int nranks, ShardComm** out) {
+  if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(MGCMT_ERR_INVALID, "bad rank / nranks");
+  if (p->dim != 2) return fail(MGCMT_ERR_UNSUPPORTED, "only 2-D plans are sharded");
+  if (p->nvec != 1) return fail(MGCMT_ERR_UNSUPPORTED, "a sharded plan holds one vector");
+  comm_release(p);
+  MG_HIP(hipSetDevice(p->device));
+  ShardComm* c = new ShardComm();
+  c->rank = rank;
+  c->nranks = nranks;
+  p->comm = c;
+  hipError_t e = hipStreamCreate(&c->comm_stream);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_boundary);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_red, sizeof(double) * 64);
+  if (e != hipSuccess) {
+    comm_release(p);
+    return fail(MGCMT_ERR_HIP, std::string("communicator resources: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return MGCMT_OK;
+}
+
+int mgcmt_comm_init(mgcmt_plan* p, int rank, int nranks, const void* unique_id) {
+  if (!unique_id) return fail(MGCMT_ERR_INVALID, "null unique id");
+  RcclApi* api = rccl();
+  if (!api) return fail(MGCMT_ERR_UNSUPPORTED, "RCCL is not available in this process");
+  ShardComm* c = nullptr;
+  MG_TRY(comm_common(p, rank, nranks, &c));
+  RcclUniqueId id;
+  memcpy(id.internal, unique_id, MGCMT_UNIQUE_ID_BYTES);
+  const int r = api->CommInitRank(&c->nccl, nranks, id, rank);
+  if (r != kRcclSuccess) {
+    c->nccl = nullptr;
+    comm_release(p);
+    return fail(MGCMT_ERR_HIP, std::string("ncclCommInitRank: ") + api->GetErrorString(r));
+  }
+  return MGCMT_OK;
+}
+
+int mgcmt_comm_init_external(mgcmt_plan* p, int rank, int nranks, mgcmt_p2p_fn p2p, mgcmt_allgather_fn allgather,
+                             mgcmt_allreduce_fn allreduce, void* user) {
+  if (nranks > 1 && (!p2p || !allgather)) return fail(MGCMT_ERR_INVALID, "missing transport callbacks");
+  ShardComm* c = nullptr;
+  MG_TRY(comm_common(p, rank, nranks, &c));
+  c->p2p = p2p;
+  c->allgather = allgather;
+  c->allreduce = allreduce;
+  c->user = user;
+  c->overlap = false;
+  return MGCMT_OK;
+}
+
+int mgcmt_comm_destroy(mgcmt_plan* p) {
+  if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
+  comm_release(p);
+  return MGCMT_OK;
+}
+
+int mgcmt_comm_set_option(mgcmt_plan* p, int option, int value) {
+  MG_TRY(check_comm(p));
+  if (option == MGCMT_COMM_OPT_OVERLAP) p->comm->overlap = value != 0 && p->comm->nccl != nullptr;
+  else if (option == MGCMT_COMM_OPT_SPLIT) p->comm->split = value != 0;
+  else if (option == MGCMT_COMM_OPT_SELF_RING) {
+    if (value && p->comm->nranks != 1) return fail(MGCMT_ERR_INVALID, "the self-ring test mode needs a one-rank communicator");
+    p->comm->self_ring = value != 0;
+  }
+  else return fail(MGCMT_ERR_INVALID, "unknown communicator option");
+  return MGCMT_OK;
+}
+
+int mgcmt_halo_exchange(mgcmt_plan* p, int l, int slot_mask, void* stream) {
+  MG_TRY(check_comm(p));
+  if (l < 0 || l >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "level out of range");
+  const bool ring = (slot_mask & kRing) != 0;
+  if (ring && p->comm->nranks != 1) return fail(MGCMT_ERR_INVALID, "the ring self-test needs a one-rank communicator");
+  hipStream_t s = (hipStream_t)stream;
+  MG_TRY(join_exchange(p, s));
+  std::vector<Msg> msgs;
+  for (int slot = 0; slot < 4; ++slot)
+    if (slot_mask & (1 << slot)) MG_TRY(halo_msgs(p, l, slot, ring, &msgs));
+  return run_msgs(p, msgs, s);
+}
+
+int mgcmt_gather_coarse(mgcmt_plan* p, int l, int slot, mgcmt_plan* coarse, int dst_slot, void* stream) {
+  MG_TRY(check_comm(p));
+  if (!coarse) return fail(MGCMT_ERR_INVALID, "null coarse plan");
+  if (l < 0 || l >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "level out of range");
+  ShardComm* c = p->comm;
+  hipStream_t s = (hipStream_t)stream;
+  MG_TRY(join_exchange(p, s));
+  MG_TRY(ensure_slot(p, l, slot));
+  MG_TRY(ensure_slot(coarse, 0, dst_slot));
+  const Level& L = p->levels[l];
+  const Level& C = coarse->levels[0];
+  if (C.nr != C.gr || C.gc != L.gc || L.nr * c->nranks != C.gr)
+    return fail(MGCMT_ERR_INVALID, "coarse plan's finest level is not the whole grid of this strip level");
+  const size_t cnt = (size_t)L.nr * L.gc;
+  double* mine = p->kvec(l, slot).p;
+  double* whole = coarse->kvec(0, dst_slot).p;
+  if (c->nranks == 1) {
+    MG_HIP(hipMemcpyAsync(whole, mine, cnt * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return MGCMT_OK;
+  }
+  if (c->nccl) {
+    RcclApi* api = rccl();
+    MG_RCCL(api, api->AllGather(mine, whole, cnt, kRcclFloat64, c->nccl, s));
+    return MGCMT_OK;
+  }
+  if (!c->allgather) return fail(MGCMT_ERR_INVALID, "communicator has no all-gather transport");
+  MG_HIP(hipStreamSynchronize(s));
+  if (c->allgather(c->user, mine, whole, (int64_t)cnt) != 0) return fail(MGCMT_ERR_HIP, "external all-gather transport failed");
+  return MGCMT_OK;
+}
+
+int mgcmt_allreduce_sum(mgcmt_plan* p, double* host_inout, int n, void* stream) {
+  MG_TRY(check_comm(p));
+  if (!host_inout || n < 1 || n > 64) return fail(MGCMT_ERR_INVALID, "allreduce: 1..64 values");
+  ShardComm* c = p->comm;
+  hipStream_t s = (hipStream_t)stream;
+  if (c->nranks == 1) return MGCMT_OK;
+  if (c->nccl) {
+    RcclApi* api = rccl();
+    MG_HIP(hipMemcpyAsync(c->d_red, host_inout, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    MG_RCCL(api, api->AllReduce(c->d_red, c->d_red, (size_t)n, kRcclFloat64, kRcclSum, c->nccl, s));
+    MG_HIP(hipMemcpyAsync(host_inout, c->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    MG_HIP(hipStreamSynchronize(s));
+    return MGCMT_OK;
+  }
+  if (!c->allreduce) return fail(MGCMT_ERR_INVALID, "communicator has no all-reduce transport");
+  if (c->allreduce(c->user, host_inout, n) != 0) return fail(MGCMT_ERR_HIP, "external all-reduce transport failed");
+  return MGCMT_OK;
+}
+
+// One V(nu1,nu2) cycle of the sharded hierarchy: `p` holds levels 0 .. ls-1 as row strips (and level ls as the strip
+// buffer the last restriction writes and the first prolongation reads), `coarse` holds the grid of level ls WHOLE on
+// every rank.  MGCMTSolver.py:281-329 with its recursion unrolled; weighted Jacobi and multicolour Gauss-Seidel are
+// order-independent, so this is the single-GPU cycle's arithmetic.
+int mgcmt_sharded_vcycle(mgcmt_plan* p, mgcmt_plan* coarse, int nu1, int nu2, int nu_coarse, int kind, double omega, int flags,
+                         void* stream) {
+  MG_TRY(check_comm(p));
+  if (!coarse) return fail(MGCMT_ERR_INVALID, "null coarse plan");
+  if (kind != MGCMT_WJACOBI && kind != MGCMT_GS_MC)
+    return fail(MGCMT_ERR_UNSUPPORTED, "only weighted Jacobi and multicolour Gauss-Seidel shard; lexicographic sweeps are sequential");
+  if (nu1 < 1 || nu2 < 1 || nu_coarse < 1) return fail(MGCMT_ERR_INVALID, "the sharded cycle needs at least one sweep per leg");
+  const int ls = (int)p->levels.size() - 1;  // strip levels 0 .. ls-1
+  if (ls < 1) return fail(MGCMT_ERR_INVALID, "strip plan has no level below the finest one");
+  ShardComm* c = p->comm;
+  hipStream_t s = (hipStream_t)stream;
+  for (int l = 0; l <= ls; ++l) {
+    MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
+    MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
+    if (l < ls) MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
+    if (l < ls && !fused_level(p, l, kind)) return fail(MGCMT_ERR_UNSUPPORTED, "a strip level is not covered by the fused kernels");
+  }
+  // what the first pass reads from the neighbours: V (unless the caller vouches that nothing changed it since the
+  // previous sharded cycle, whose last pass exchanged it) and, once per right-hand side, F
+  {
+    int mask = 0;
+    if (!(flags & MGCMT_SHARDED_V_HALO_VALID)) mask |= 1 << MGCMT_SLOT_V;
+    if (!(flags & MGCMT_SHARDED_F_HALO_VALID)) mask |= 1 << MGCMT_SLOT_F;
+    if (mask) MG_TRY(mgcmt_halo_exchange(p, 0, mask | (c->self_ring ? kRing : 0), stream));
+  }
+  std::vector<int> recompute(ls, 0);
+  std::vector<char> still_zero(ls, 0);
+  for (int l = 0; l < ls; ++l) {
+    const int nu = l == 0 ? nu1 : nu_coarse, nu_up = l == 0 ? nu2 : nu_coarse;
+    const std::vector<int> passes = split_sweeps(p, l, kind, nu);
+    const int first_up = split_sweeps(p, l, kind, nu_up)[0];
+    for (size_t i = 0; i < passes.size(); ++i) {
+      const bool last = i + 1 == passes.size();
+      const bool zero_in = i == 0 && l > 0;  // the coarse iterate starts at zero: nothing to read or exchange
+      int mode = last ? 2 : 0;
+      // recompute instead of store (bandwidth-bound levels): the last down-leg pass writes only the restricted
+      // residual, the first up-leg pass re-runs its sweeps from the untouched V (whose halo rows stay valid)
+      const bool big = p->force_recompute || p->interior(l) >= (1L << 22);
+      if (last && p->use_recompute && big &&
+          passes[i] <= fused_max_recompute(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0, first_up)) {
+        mode |= 8;
+        recompute[l] = passes[i];
+        still_zero[l] = zero_in;
+      }
+      MG_TRY(strip_pass(p, l, kind, passes[i], omega, mode | (zero_in ? 4 : 0), 0, s, l + 1 < ls));
+    }
+  }
+  // the coarse problem: all-gather, the same sub-cycle on every rank, own rows of the correction with halo rows
+  MG_TRY(mgcmt_gather_coarse(p, ls, MGCMT_SLOT_F, coarse, MGCMT_SLOT_F, stream));
+  MG_TRY(ensure_slot(coarse, 0, MGCMT_SLOT_V));
+  launch_fill(s, coarse->kvec(0, MGCMT_SLOT_V).p, coarse->interior(0), 0.0);
+  MG_TRY(mgcmt_vcycle(coarse, 0, nu_coarse, nu_coarse, nu_coarse, kind, omega, 1, 0, stream));
+  {
+    const Level& L = p->levels[ls];
+    const long total = L.gr;
+    const long lo = std::max<long>(L.r0 - kHalo, 0), hi = std::min<long>(L.r0 + L.nr + kHalo, total);
+    MG_HIP(hipMemcpyAsync(p->kvec(ls, MGCMT_SLOT_V).p + (lo - L.r0) * L.gc, coarse->kvec(0, MGCMT_SLOT_V).p + lo * L.gc,
+                          sizeof(double) * (size_t)(hi - lo) * L.gc, hipMemcpyDeviceToDevice, s));
+  }
+  for (int l = ls - 1; l >= 0; --l) {
+    const std::vector<int> passes = split_sweeps(p, l, kind, l == 0 ? nu2 : nu_coarse);
+    for (size_t i = 0; i < passes.size(); ++i) {
+      const int mode = i == 0 ? (1 | (still_zero[l] ? 4 : 0)) : 0;
+      MG_TRY(strip_pass(p, l, kind, passes[i], omega, mode, i == 0 ? recompute[l] : 0, s, false));
+    }
+  }
+  // leave nothing running beside the caller's stream
+  MG_TRY(join_exchange(p, s));
+  (void)c;
+  return post_launch();
+}
+
+}  // extern "C"

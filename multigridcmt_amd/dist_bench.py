@@ -7,13 +7,32 @@ import time
 import numpy as np
 
 
+def _init_group(backend, rank, world, local, on_gpu):
+    """torch.distributed is the control plane (rendezvous, barriers, the maximum of the rank times); the store it
+    rendezvouses through also carries the RCCL communicator id of the data path."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, rank == 0,
+                          timeout=datetime.timedelta(seconds=300))
+    if on_gpu:
+        torch.cuda.set_device(local)
+        try:
+            dist.init_process_group(backend, store=store, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        except TypeError:                                   # older signature without device_id
+            dist.init_process_group(backend, store=store, rank=rank, world_size=world)
+    else:
+        dist.init_process_group(backend, store=store, rank=rank, world_size=world)
+    return store
+
+
 def run(args, backend="nccl", on_gpu=True):
     """backend / on_gpu exist for the CPU rehearsal of this very function (tests/test_distributed.py: gloo, host memory,
     emulated kernels); bench.py always calls it with the defaults."""
     import torch
     import torch.distributed as dist
     from . import _lib
-    from .distributed import ShardedPlan
+    from .distributed import ShardedPlan, rccl_unique_id
     from .operators import laplacian_operator
 
     rank = int(os.environ.get("RANK", "0"))
@@ -21,22 +40,23 @@ def run(args, backend="nccl", on_gpu=True):
     os.environ.setdefault("MASTER_PORT", "29533")
     local = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if on_gpu:
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    store = _init_group(backend, rank, world, local, on_gpu)
+    transport = getattr(args, "transport", "rccl") if on_gpu else "torch"
+    uid = None
+    if transport == "rccl":
+        if rank == 0:
+            store.set("mgcmt_rccl_id", rccl_unique_id())
+        uid = bytes(store.get("mgcmt_rccl_id"))
     g = args.grid
     kind = _lib.WJACOBI if args.smoother == "wjacobi" else _lib.GS_MC
     omega = 2.0 / 3.0 if args.smoother == "wjacobi" else 1.0
     op = laplacian_operator(g, "2d") * (-1.0 / np.pi ** 2)
-    sp = ShardedPlan(op, args.lowest, rank, world, device=local, switch_grid=getattr(args, "switch_grid", None), on_gpu=on_gpu)
+    sp = ShardedPlan(op, args.lowest, rank, world, device=local, switch_grid=getattr(args, "switch_grid", None), on_gpu=on_gpu,
+                     transport=transport, unique_id=uid)
     sp.set_shift(0.0)
     rows = g // world
-    f = np.random.RandomState(1 + rank).rand(rows * g)
-    sp.upload_local(_lib.SLOT_F, f)
-    sp.plan.fill(0, _lib.SLOT_V, 0, 0.0)
-    del f
+    sp.upload_local(_lib.SLOT_F, np.random.RandomState(1 + rank).rand(rows * g))   # this rank's rows of the right-hand side
+    sp.fill_local(_lib.SLOT_V, 0.0)
 
     def cycle():
         sp.vcycle(args.nu, args.nu, kind, omega=omega, nu_coarse=args.nu)
@@ -74,9 +94,10 @@ def run(args, backend="nccl", on_gpu=True):
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "2D Laplacian %d^2 fp64, V(%d,%d) %s, lowest_level %d, %dxMI355X row strips down to %d^2, "
-                                   "RCCL halo exchange" % (g, args.nu, args.nu, args.smoother, args.lowest, world, sp.switch),
+                                   "%s halo exchange" % (g, args.nu, args.nu, args.smoother, args.lowest, world, sp.switch,
+                                                         "RCCL (in libmgcmt_hip.so, overlapped with the interior launches)" if transport == "rccl" else "torch.distributed"),
                        "grid": g, "smoother": args.smoother, "nu1": args.nu, "nu2": args.nu, "lowest_level": args.lowest,
-                       "parallelism": "strips%d" % world, "strip_levels": sp.strip_levels},
+                       "parallelism": "strips%d" % world, "strip_levels": sp.strip_levels, "transport": transport},
             "vcycles_per_s": args.steps / elapsed,
         }
         print(json.dumps(out), flush=True)

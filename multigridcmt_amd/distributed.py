@@ -1,30 +1,39 @@
 """Sharded V-cycle: the finest levels as row strips across ranks, one process per GPU.
 
-Rank r owns rows [r*g/P, (r+1)*g/P) of every strip level.  Between two fused passes the
-ranks exchange MGCMT_HALO_ROWS halo rows of V (and once per level of F) with their chain neighbours through
-``torch.distributed`` point-to-point calls — RCCL over xGMI on GPUs, gloo in the CPU tests — and the fused
-kernels recompute the few overlap rows redundantly, so one exchange serves a whole pass (two sweeps and a
-transfer).  Below the switch level every rank holds the WHOLE coarse problem: one all-gather assembles the
-restricted residual on all ranks, each runs the rest of the cycle redundantly with ``mgcmt_vcycle`` (a captured
-HIP graph, identical arithmetic everywhere) and takes its own rows (with halo rows) of the correction — no rank
-waits for another one's coarse solve and nothing has to be sent back.  Weighted Jacobi and the
-multicolour Gauss-Seidel are order-independent, so the sharded cycle computes what the single-GPU cycle
-computes (tests/test_distributed.py); the lexicographic smoothers do not shard.
+Rank r owns rows [r*g/P, (r+1)*g/P) of every strip level.  The cycle itself — which pass runs when,
+what is exchanged after it, the all-gather in front of the coarse problem — is ``mgcmt_sharded_vcycle`` of
+libmgcmt_hip.so (csrc/sharded.hip); this module only builds the two plans (strips + the whole coarse grid that every
+rank solves redundantly), hands the library a transport and keeps track of which halo rows are still valid.
 
-PyTorch is plumbing here: tensors are zero-copy views of the plan's device memory (mgcmt_vec_ptr).
+Transports
+* ``"rccl"``  — the library calls RCCL itself (ncclSend/ncclRecv groups, ncclAllGather on HIP streams; no Python, no
+  host synchronisation inside a cycle; the exchange of a pass's boundary rows overlaps its interior launch).  The
+  128-byte communicator id comes from rank 0 (``rccl_unique_id``) through any channel the host program has — bench.py
+  uses the torch.distributed store.
+* ``"torch"`` — callbacks into ``torch.distributed`` point-to-point / all-gather (gloo in the CPU tests, where "device"
+  memory is host memory of the emulated kernels; gloo with staging through host memory for several ranks on one GPU).
+
+Weighted Jacobi and the multicolour Gauss-Seidel are order-independent, so the sharded cycle computes what the
+single-GPU cycle computes (tests/test_distributed.py); the lexicographic smoothers do not shard.
 """
 import ctypes
-import os
 
 import numpy as np
 
 from . import _lib
-from ._lib import GS_MC, HALO_ROWS, SLOT_F, SLOT_T, SLOT_V, WJACOBI
+from ._lib import GS_MC, HALO_ROWS, SLOT_F, SLOT_T, SLOT_V, WJACOBI, check
 from .plan import Plan
 
 
 def _log2(x):
     return int(x).bit_length() - 1
+
+
+def rccl_unique_id():
+    """128 bytes naming a new RCCL communicator (call on ONE rank, distribute to all)."""
+    buf = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+    check(_lib.lib().mgcmt_comm_unique_id(buf))
+    return buf.raw
 
 
 class _DevicePointer:
@@ -35,20 +44,89 @@ class _DevicePointer:
                                          "strides": None}
 
 
-class ShardedPlan:
-    def __init__(self, op, lowest, rank, world, device=0, switch_grid=None, on_gpu=True):
+class _TorchTransport:
+    """The external-transport callbacks of mgcmt_comm_init_external on top of torch.distributed."""
+
+    def __init__(self, device, on_gpu):
         import torch
         import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        if on_gpu and not torch.cuda.is_available():
-            raise _lib.MgcmtError(
-                "PyTorch sees no GPU.  In a process that uses both, import torch BEFORE the first call into "
-                "libmgcmt_hip.so: each brings a HIP runtime and only the first one loaded can open the device.")
-        self.rank, self.world, self.on_gpu = rank, world, on_gpu
-        self.device = device
-        # gloo moves host memory only: with device-resident strips (rehearsing several ranks on one GPU, or a box
-        # without RCCL) every message is staged through a host tensor.  RCCL (backend "nccl") sends device memory.
+        self.torch, self.dist, self.device, self.on_gpu = torch, dist, device, on_gpu
+        # gloo moves host memory only: device-resident strips are staged through host tensors
         self.stage_host = bool(on_gpu and dist.is_initialized() and dist.get_backend() == "gloo")
+        self.error = None
+        self.p2p = _lib.P2P_FN(self._p2p)
+        self.allgather = _lib.ALLGATHER_FN(self._allgather)
+        self.allreduce = _lib.ALLREDUCE_FN(self._allreduce)
+
+    def _tensor(self, ptr, count):
+        if self.on_gpu:
+            return self.torch.as_tensor(_DevicePointer(ptr, count), device="cuda:%d" % self.device)
+        buf = (ctypes.c_double * count).from_address(ptr)
+        return self.torch.from_numpy(np.ctypeslib.as_array(buf))
+
+    def _p2p(self, user, nops, ops):
+        try:
+            dist, torch = self.dist, self.torch
+            sends = [(self._tensor(ops[i].ptr, ops[i].count), ops[i].peer) for i in range(nops) if ops[i].is_send]
+            recvs = [(self._tensor(ops[i].ptr, ops[i].count), ops[i].peer) for i in range(nops) if not ops[i].is_send]
+            if self.stage_host:
+                staged = [torch.empty(v.shape, dtype=v.dtype, device="cpu") for v, _ in recvs]
+                batch = [dist.P2POp(dist.isend, v.cpu(), peer) for v, peer in sends]
+                batch += [dist.P2POp(dist.irecv, h, peer) for (_, peer), h in zip(recvs, staged)]
+                for w in dist.batch_isend_irecv(batch):
+                    w.wait()
+                for (v, _), h in zip(recvs, staged):
+                    v.copy_(h)
+                if self.on_gpu:
+                    torch.cuda.synchronize()
+                return 0
+            batch = [dist.P2POp(dist.isend, v, peer) for v, peer in sends] + [dist.P2POp(dist.irecv, v, peer) for v, peer in recvs]
+            for w in dist.batch_isend_irecv(batch):
+                w.wait()
+            if self.on_gpu:
+                torch.cuda.synchronize()
+            return 0
+        except Exception as e:                                   # an exception must not unwind through the C frames
+            self.error = e
+            return -1
+
+    def _allgather(self, user, send, recv, count):
+        try:
+            dist, torch = self.dist, self.torch
+            world = dist.get_world_size()
+            mine = self._tensor(send, count)
+            whole = self._tensor(recv, count * world)
+            parts = [whole[r * count:(r + 1) * count] for r in range(world)]
+            if self.stage_host:
+                host = [torch.empty(mine.shape, dtype=mine.dtype, device="cpu") for _ in range(world)]
+                dist.all_gather(host, mine.cpu())
+                for view, h in zip(parts, host):
+                    view.copy_(h)
+            else:
+                dist.all_gather(parts, mine)
+            if self.on_gpu:
+                torch.cuda.synchronize()
+            return 0
+        except Exception as e:
+            self.error = e
+            return -1
+
+    def _allreduce(self, user, inout, n):
+        try:
+            arr = np.ctypeslib.as_array(inout, shape=(n,))
+            dev = ("cuda:%d" % self.device) if self.on_gpu and not self.stage_host else "cpu"
+            t = self.torch.tensor(arr.copy(), dtype=self.torch.float64, device=dev)
+            self.dist.all_reduce(t)
+            arr[:] = t.cpu().numpy()
+            return 0
+        except Exception as e:
+            self.error = e
+            return -1
+
+
+class ShardedPlan:
+    def __init__(self, op, lowest, rank, world, device=0, switch_grid=None, on_gpu=True, transport="torch", unique_id=None):
+        self.rank, self.world, self.on_gpu, self.device = rank, world, on_gpu, device
         if op.dimension != "2d":
             raise ValueError("only 2-D problems are sharded")
         g = op.g
@@ -58,9 +136,9 @@ class ShardedPlan:
         if switch_grid is None:
             # below this grid the cycle is cheaper run whole on every rank than as strips with two more exchanges per
             # level: a 2048^2 cycle costs 0.2 ms on one GPU and its all-gather moves 32 MiB; one level up it would be
-            # 0.34 ms and 128 MiB (~0.3 ms over xGMI), more than the two exchanges (~0.1 ms each) it saves
+            # 0.34 ms and 128 MiB (~0.3 ms over xGMI), more than the two exchanges it saves
             switch_grid = max(2048, 64 * world)
-        # strip levels: grids above the switch size; every strip must keep >= 2*HALO_ROWS rows and even bounds
+        # strip levels: grids above the switch size; every strip must keep >= 4*HALO_ROWS rows and even bounds
         ls = 0
         while ls < nlev_total - 1 and (g >> ls) > switch_grid and ((g >> ls) // world) >= 4 * HALO_ROWS:
             ls += 1
@@ -76,100 +154,53 @@ class ShardedPlan:
         self.g, self.switch = g, g >> ls
         # every rank continues from the switch level on the whole grid (redundantly)
         from .operators import StructuredOperator
-        terms = []
-        xf = self.plan.factors(ls, 0)
-        yf = self.plan.factors(ls, 1)
-        for m in range(xf.shape[0]):
-            terms.append((xf[m].copy(), yf[m].copy()))
+        xf, yf = self.plan.factors(ls, 0), self.plan.factors(ls, 1)
+        terms = [(xf[m].copy(), yf[m].copy()) for m in range(xf.shape[0])]
         self.coarse = Plan(StructuredOperator("2d", self.switch, terms), lowest, nvec=1, device=device)
-        self._views = {}
-        self._fine_rhs_halo_valid = False
-        self.use_recompute = True
-        self.recompute_min_points = 1 << 22          # per-rank level size from which recomputing beats storing
+        self.transport = transport
+        self._torch_transport = None
+        L = _lib.lib()
+        if transport == "rccl":
+            if unique_id is None or len(unique_id) != _lib.UNIQUE_ID_BYTES:
+                raise ValueError("the RCCL transport needs the %d-byte id of rccl_unique_id() from rank 0" % _lib.UNIQUE_ID_BYTES)
+            check(L.mgcmt_comm_init(self.plan._h, rank, world, ctypes.create_string_buffer(unique_id, _lib.UNIQUE_ID_BYTES)))
+        elif transport == "torch":
+            import torch
+            if on_gpu and not torch.cuda.is_available():
+                raise _lib.MgcmtError(
+                    "PyTorch sees no GPU.  In a process that uses both, import torch BEFORE the first call into "
+                    "libmgcmt_hip.so: each brings a HIP runtime and only the first one loaded can open the device.")
+            t = self._torch_transport = _TorchTransport(device, on_gpu)
+            check(L.mgcmt_comm_init_external(self.plan._h, rank, world, t.p2p, t.allgather, t.allreduce, None))
+        else:
+            raise ValueError("transport must be 'rccl' or 'torch'")
+        self._v_halo_valid = False
+        self._f_halo_valid = False
 
-    # -- zero-copy tensor views of plan memory ------------------------------------------------------
-    def _flat(self, plan, level, slot):
-        """1-D tensor over vector 0 of (plan, level, slot) INCLUDING its halo rows."""
-        key = (id(plan), level, slot, plan.vec_ptr(level, slot, 0))
-        t = self._views.get(key)
-        if t is None:
-            rows, cols, _ = plan.shapes[level]
-            ptr = plan.vec_ptr(level, slot, 0) - HALO_ROWS * cols * 8
-            count = (rows + 2 * HALO_ROWS) * cols
-            if self.on_gpu:
-                t = self.torch.as_tensor(_DevicePointer(ptr, count), device="cuda:%d" % self.device)
-            else:
-                buf = (ctypes.c_double * count).from_address(ptr)
-                t = self.torch.from_numpy(np.ctypeslib.as_array(buf))
-            self._views[key] = t
-        return t
+    def _check(self, rc):
+        t = self._torch_transport
+        if rc != 0 and t is not None and t.error is not None:
+            err, t.error = t.error, None
+            raise err
+        check(rc)
 
-    def rows_view(self, plan, level, slot, first_row, nrows):
-        """Tensor view of rows [first_row, first_row+nrows) (local indices; negative = upper halo)."""
-        _, cols, _ = plan.shapes[level]
-        flat = self._flat(plan, level, slot)
-        a = (first_row + HALO_ROWS) * cols
-        return flat[a:a + nrows * cols]
+    def set_comm_option(self, option, value):
+        check(_lib.lib().mgcmt_comm_set_option(self.plan._h, option, int(value)))
 
     # -- communication ------------------------------------------------------------------------------
-    def _run_p2p(self, sends, recvs):
-        """One batch of point-to-point operations: sends / recvs are lists of (tensor view, peer rank)."""
-        dist = self.dist
-        if not sends and not recvs:
-            return
-        if self.stage_host:
-            staged = [(view, self.torch.empty(view.shape, dtype=view.dtype, device="cpu")) for view, _ in recvs]
-            ops = [dist.P2POp(dist.isend, view.cpu(), peer) for view, peer in sends]
-            ops += [dist.P2POp(dist.irecv, host, peer) for (_, peer), (_, host) in zip(recvs, staged)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            for view, host in staged:
-                view.copy_(host)
-            return
-        ops = [dist.P2POp(dist.isend, view, peer) for view, peer in sends] + [dist.P2POp(dist.irecv, view, peer) for view, peer in recvs]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-
-    def exchange_halo(self, *pairs):
-        """Fill the halo rows of every (level, slot) in `pairs` with the neighbours' boundary rows (chain
-        topology), all in ONE batch of point-to-point operations."""
-        H = HALO_ROWS
-        sends, recvs = [], []
-        up, down = self.rank - 1, self.rank + 1
+    def exchange_halo(self, *pairs, ring=False):
+        """Fill the halo rows of every (level, slot) in `pairs` with the neighbours' boundary rows (chain topology);
+        one batch per level."""
+        by_level = {}
         for level, slot in pairs:
-            rows = self.plan.shapes[level][0]
-            if up >= 0:
-                sends.append((self.rows_view(self.plan, level, slot, 0, H), up))
-                recvs.append((self.rows_view(self.plan, level, slot, -H, H), up))
-            if down < self.world:
-                sends.append((self.rows_view(self.plan, level, slot, rows - H, H), down))
-                recvs.append((self.rows_view(self.plan, level, slot, rows, H), down))
-        self._run_p2p(sends, recvs)
+            by_level[level] = by_level.get(level, 0) | (1 << slot)
+        for level, mask in sorted(by_level.items()):
+            self._check(_lib.lib().mgcmt_halo_exchange(self.plan._h, level, mask | (_lib.HALO_RING if ring else 0), None))
 
-    def gather_all(self, level, slot, dst_slot):
-        """Strips of (level, slot) -> the whole-grid level 0 of every rank's coarse plan (one all-gather)."""
-        dist = self.dist
-        rows = self.plan.shapes[level][0]
-        mine = self.rows_view(self.plan, level, slot, 0, rows)
-        parts = [self.rows_view(self.coarse, 0, dst_slot, r * rows, rows) for r in range(self.world)]
-        if self.world == 1:
-            parts[0].copy_(mine)
-        elif self.stage_host:
-            host = [self.torch.empty(mine.shape, dtype=mine.dtype, device="cpu") for _ in range(self.world)]
-            dist.all_gather(host, mine.cpu())
-            for view, h in zip(parts, host):
-                view.copy_(h)
-        else:
-            dist.all_gather(parts, mine)
-
-    def take_own_rows(self, level, slot, src_slot):
-        """This rank's rows of the coarse plan's whole-grid vector -> (level, slot), including the halo rows that
-        exist (a local copy)."""
-        H = HALO_ROWS
-        rows = self.plan.shapes[level][0]
-        total = rows * self.world
-        lo, hi = max(self.rank * rows - H, 0), min((self.rank + 1) * rows + H, total)
-        self.rows_view(self.plan, level, slot, lo - self.rank * rows, hi - lo).copy_(self.rows_view(self.coarse, 0, src_slot, lo, hi - lo))
+    def allreduce_sum(self, values):
+        a = np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy()
+        self._check(_lib.lib().mgcmt_allreduce_sum(self.plan._h, _lib.as_dp(a), a.size, None))
+        return a
 
     # -- data ---------------------------------------------------------------------------------------
     def set_shift(self, mu):
@@ -179,8 +210,18 @@ class ShardedPlan:
     def upload_local(self, slot, host_rows):
         """This rank's rows of a fine-level vector (host array of local_rows*g doubles)."""
         self.plan.upload(0, slot, 0, host_rows)
+        self.invalidate(slot)
+
+    def fill_local(self, slot, value):
+        self.plan.fill(0, slot, 0, value)
+        self.invalidate(slot)
+
+    def invalidate(self, slot):
+        """Call after anything but vcycle() changed the fine level's V or F: their halo rows travel again."""
         if slot == SLOT_F:
-            self._fine_rhs_halo_valid = False
+            self._f_halo_valid = False
+        if slot == SLOT_V:
+            self._v_halo_valid = False
 
     def download_local(self, slot):
         return self.plan.download(0, slot, 0)
@@ -189,17 +230,6 @@ class ShardedPlan:
         self.plan.sync()
 
     # -- the cycle ----------------------------------------------------------------------------------
-    def _passes(self, level, kind, nu):
-        cap = self.plan.fused_max_sweeps(level, kind)
-        if cap < 1:
-            raise _lib.MgcmtError("strip level %d is not covered by the fused kernels" % level)
-        out, left = [], nu
-        while left > 0:
-            n = min(cap, left)
-            out.append(n)
-            left -= n
-        return out
-
     def vcycle(self, nu1, nu2, kind, omega=1.0, nu_coarse=None):
         """One V(nu1,nu2) cycle on V, F of the fine level (sharded down to the switch grid)."""
         if kind not in (WJACOBI, GS_MC):
@@ -207,64 +237,22 @@ class ShardedPlan:
         if nu1 < 1 or nu2 < 1:
             raise ValueError("the sharded cycle needs at least one pre- and one post-smoothing sweep")
         nu_coarse = nu1 if nu_coarse is None else nu_coarse
-        P, ls = self.plan, self.strip_levels
-        recompute, still_zero = [0] * ls, [False] * ls
-        for l in range(ls):
-            nu, nu_up = (nu1, nu2) if l == 0 else (nu_coarse, nu_coarse)
-            passes = self._passes(l, kind, nu)
-            first_up = self._passes(l, kind, nu_up)[0]
-            for i, n in enumerate(passes):
-                last = i == len(passes) - 1
-                zero_in = i == 0 and l > 0                 # the coarse iterate starts at zero: nothing to read or exchange
-                if i == 0 and l == 0:
-                    # F of the fine level is constant between uploads: its halo rows travel once
-                    if self._fine_rhs_halo_valid:
-                        self.exchange_halo((0, SLOT_V))
-                    else:
-                        self.exchange_halo((0, SLOT_V), (0, SLOT_F))
-                        self._fine_rhs_halo_valid = True
-                elif i == 0:
-                    self.exchange_halo((l, SLOT_F))
-                else:
-                    self.exchange_halo((l, SLOT_V))
-                mode = 2 if last else 0
-                # recompute instead of store (bandwidth-bound levels): the last down-leg pass writes only the
-                # restricted residual, the first up-leg pass re-runs its sweeps from the untouched V
-                if last and self.use_recompute and P.size(l) >= self.recompute_min_points and n <= P.fused_max_recompute(l, kind, first_up):
-                    mode |= 8
-                    recompute[l], still_zero[l] = n, zero_in
-                P.fused_pass(l, kind, n, omega=omega, mode=mode | (4 if zero_in else 0))
-        # the coarse problem: all-gather, the same sub-cycle on every rank, own rows of the correction with halo rows
-        self.gather_all(ls, SLOT_F, SLOT_F)
-        self.coarse.vcycle(nu_coarse, nu_coarse, kind, omega=omega, k=1, nu_coarse=nu_coarse, level=0, zero_start=True)
-        self.take_own_rows(ls, SLOT_V, SLOT_V)
-        for l in range(ls - 1, -1, -1):
-            nu = nu2 if l == 0 else nu_coarse
-            passes = self._passes(l, kind, nu)
-            for i, n in enumerate(passes):
-                need = []
-                if i == 0 and l + 1 < ls:
-                    need.append((l + 1, SLOT_V))           # the correction to interpolate
-                if not (i == 0 and recompute[l]):
-                    need.append((l, SLOT_V))               # (a recomputing pass reads the V whose halo rows are still valid)
-                if need:
-                    self.exchange_halo(*need)
-                mode = (1 | (4 if still_zero[l] else 0) | (recompute[l] << 4)) if i == 0 else 0
-                P.fused_pass(l, kind, n, omega=omega, mode=mode)
+        flags = (_lib.SHARDED_V_HALO_VALID if self._v_halo_valid else 0) | (_lib.SHARDED_F_HALO_VALID if self._f_halo_valid else 0)
+        self._check(_lib.lib().mgcmt_sharded_vcycle(self.plan._h, self.coarse._h, nu1, nu2, nu_coarse, kind,
+                                                    ctypes.c_double(omega), flags, None))
+        self._v_halo_valid = self._f_halo_valid = True
 
     def residual_norm(self):
         """|| F - (A - mu I) V ||_2 over all ranks."""
         P = self.plan
-        self.exchange_halo((0, SLOT_V))
+        if not self._v_halo_valid:
+            self.exchange_halo((0, SLOT_V))
+            self._v_halo_valid = True
         P.apply(0, (SLOT_V, 0), (SLOT_T, 0), with_shift=True)
         P.axpy(0, -1.0, (SLOT_F, 0), (SLOT_T, 0))
         local = P.dot(0, (SLOT_T, 0), (SLOT_T, 0))
-        t = self.torch.tensor([local], dtype=self.torch.float64,
-                              device=("cuda:%d" % self.device) if self.on_gpu and not self.stage_host else "cpu")
-        self.dist.all_reduce(t)
-        return float(t.item()) ** 0.5
+        return float(self.allreduce_sum([local])[0]) ** 0.5
 
     def close(self):
-        self._views.clear()
         self.plan.close()
         self.coarse.close()

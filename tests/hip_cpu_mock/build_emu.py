@@ -33,7 +33,7 @@ def build(force=False):
         if p.returncode:
             sys.stderr.write(out.decode())
             raise RuntimeError("emulator build failed: " + " ".join(cmd))
-    subprocess.check_call(["g++", "-shared", "-o", OUT] + objs)
+    subprocess.check_call(["g++", "-shared", "-o", OUT] + objs + ["-ldl"])
     return OUT
 
 

@@ -147,3 +147,4 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipEventDestroy(hipEvent_t e);
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }  // everything is synchronous here

@@ -21,8 +21,8 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 kind, omega = (_lib.WJACOBI, 2. / 3.) if kind_name == "wjacobi" else (_lib.GS_MC, 1.0)
 op = laplacian_operator(g, "2d") * (-1 / np.pi ** 2)
 sp = ShardedPlan(op, 8, rank, world, device=0, switch_grid=g // 4)
-assert sp.stage_host
-sp.recompute_min_points = 0
+assert sp._torch_transport.stage_host
+sp.plan.set_option(_lib.OPT_RECOMPUTE, 2)
 sp.set_shift(0.3)
 rng = np.random.RandomState(9)
 f, v0 = rng.rand(g * g), rng.rand(g * g)

@@ -1,4 +1,12 @@
-"""Child process of tests/test_full_size_gpu.py::test_sharded_plan_single_rank_on_gpu (GPU box only)."""
+"""Child process of tests/test_full_size_gpu.py::test_sharded_plan_single_rank_on_gpu (GPU box only): the sharded
+cycle of libmgcmt_hip.so at world size 1 through its RCCL transport.
+
+1. ring self-exchange: mgcmt_halo_exchange with the rank as its own neighbour — RCCL send/recv to self must put the
+   bottom rows into the upper halo rows and the top rows into the lower halo rows (read back through torch views).
+2. the sharded cycle in self-ring mode: boundary rows first, their RCCL exchange on the second stream beside the
+   interior launch, the all-gather replaced by its one-rank copy — the result must be the single plan's.
+3. the same through the external transport (torch.distributed, backend nccl = RCCL) at world size 1.
+"""
 import os
 import socket
 import sys
@@ -10,7 +18,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from multigridcmt_amd import _lib                                   # noqa: E402
-from multigridcmt_amd.distributed import ShardedPlan                 # noqa: E402
+from multigridcmt_amd.distributed import ShardedPlan, _DevicePointer, rccl_unique_id   # noqa: E402
 from multigridcmt_amd.operators import laplacian_operator            # noqa: E402
 from multigridcmt_amd.plan import Plan                               # noqa: E402
 
@@ -22,16 +30,10 @@ os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
 g = 4096
+H = _lib.HALO_ROWS
 op = laplacian_operator(g, "2d") * (-1 / np.pi ** 2)
 f = np.random.RandomState(2).rand(g * g)
-sp = ShardedPlan(op, 8, 0, 1, device=0, switch_grid=1024)
-sp.set_shift(0.0)
-sp.upload_local(_lib.SLOT_F, f)
-sp.plan.fill(0, _lib.SLOT_V, 0, 0.0)
-for _ in range(2):
-    sp.vcycle(2, 2, _lib.GS_MC, omega=1.0, nu_coarse=2)
-got, res = sp.download_local(_lib.SLOT_V), sp.residual_norm()
-sp.close()
+
 p = Plan(op, 8, nvec=1)
 p.set_shifts([0.0])
 p.upload(0, _lib.SLOT_F, 0, f)
@@ -43,8 +45,41 @@ p.apply(0, (_lib.SLOT_V, 0), (_lib.SLOT_T, 0), with_shift=True)
 p.axpy(0, -1.0, (_lib.SLOT_F, 0), (_lib.SLOT_T, 0))
 want_res = np.sqrt(p.dot(0, (_lib.SLOT_T, 0), (_lib.SLOT_T, 0)))
 p.close()
-err = np.linalg.norm(got - want) / np.linalg.norm(want)
-print("rel err", err, "residual", res, want_res, "strip levels", sp.strip_levels)
-assert err < 1e-12 and abs(res - want_res) < 1e-9 * want_res
+
+for transport in ("rccl", "torch"):
+    sp = ShardedPlan(op, 8, 0, 1, device=0, switch_grid=1024, transport=transport,
+                     unique_id=rccl_unique_id() if transport == "rccl" else None)
+    sp.set_shift(0.0)
+    sp.upload_local(_lib.SLOT_F, f)
+    sp.fill_local(_lib.SLOT_V, 0.0)
+    if transport == "rccl":
+        # 1. ring self-exchange on levels 0 and 1 of F (level 1 of a 4096^2 / 1024 plan is a strip level too)
+        sp.plan.upload(1, _lib.SLOT_F, 0, np.arange((g // 2) ** 2, dtype=np.float64))
+        sp.exchange_halo((0, _lib.SLOT_F), ring=True)
+        sp.exchange_halo((1, _lib.SLOT_F), ring=True)
+        sp.sync()
+        for level, cols in ((0, g), (1, g // 2)):
+            rows = cols
+            base = sp.plan.vec_ptr(level, _lib.SLOT_F, 0) - H * cols * 8
+            flat = torch.as_tensor(_DevicePointer(base, (rows + 2 * H) * cols), device="cuda:0").cpu().numpy().reshape(rows + 2 * H, cols)
+            assert np.array_equal(flat[:H], flat[rows:rows + H]), "upper halo rows != bottom rows (level %d)" % level
+            assert np.array_equal(flat[rows + H:], flat[H:2 * H]), "lower halo rows != top rows (level %d)" % level
+        print("ring self-exchange through RCCL ok")
+        sp.set_comm_option(_lib.COMM_OPT_SELF_RING, 1)
+    for _ in range(2):
+        sp.vcycle(2, 2, _lib.GS_MC, omega=1.0, nu_coarse=2)
+    got, res = sp.download_local(_lib.SLOT_V), sp.residual_norm()
+    err = np.linalg.norm(got - want) / np.linalg.norm(want)
+    print(transport, "rel err", err, "residual", res, want_res, "strip levels", sp.strip_levels)
+    assert err < 1e-12 and abs(res - want_res) < 1e-9 * want_res
+    if transport == "rccl":
+        # overlap off / split off give the same numbers
+        for opt in (_lib.COMM_OPT_OVERLAP, _lib.COMM_OPT_SPLIT):
+            sp.set_comm_option(opt, 0)
+            sp.fill_local(_lib.SLOT_V, 0.0)
+            for _ in range(2):
+                sp.vcycle(2, 2, _lib.GS_MC, omega=1.0, nu_coarse=2)
+            assert np.array_equal(sp.download_local(_lib.SLOT_V), got), opt
+    sp.close()
 dist.destroy_process_group()
 print("SHARDED_WORLD1_OK")

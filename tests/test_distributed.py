@@ -1,5 +1,6 @@
-"""The sharded V-cycle (multigridcmt_amd/distributed.py) with world_size 2 and 4 on CPU: gloo for the halo
-exchange, the emulated kernels for the compute.  The sharded result must equal the single-plan result."""
+"""The sharded V-cycle (mgcmt_sharded_vcycle of csrc/sharded.hip behind multigridcmt_amd/distributed.py) with
+world_size 2 and 4 on CPU: the library's external transport carried by gloo, the emulated kernels for the compute
+(boundary rows first, then the interior rows, as on the GPU).  The sharded result must equal the single-plan result."""
 import os
 import socket
 import sys
@@ -35,7 +36,7 @@ def _worker(rank, world, port, g, kind, omega, nu, out_dir, force_recompute):
     sp = ShardedPlan(op, 8, rank, world, switch_grid=g // 4, on_gpu=False)
     sp.set_shift(0.4)
     if force_recompute:
-        sp.recompute_min_points = 0                 # take the recompute-instead-of-store passes on these small strips too
+        sp.plan.set_option(_lib.OPT_RECOMPUTE, 2)   # take the recompute-instead-of-store passes on these small strips too
     rng = np.random.RandomState(5)
     f, v0 = rng.rand(g * g), rng.rand(g * g)
     rows = g // world
@@ -95,7 +96,7 @@ def _bench_worker(rank, world, port, out_dir):
     import build_emu
     from multigridcmt_amd import _lib, dist_bench
     _lib.use_library(build_emu.build())
-    args = argparse.Namespace(grid=512, smoother="rb", nu=2, lowest=8, steps=2, warmup=1, switch_grid=128, gpus=world)
+    args = argparse.Namespace(grid=512, smoother="rb", nu=2, lowest=8, steps=2, warmup=1, switch_grid=128, gpus=world, transport="torch")
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         dist_bench.run(args, backend="gloo", on_gpu=False)

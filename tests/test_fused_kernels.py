@@ -239,36 +239,3 @@ def test_cycle_tail_in_one_launch(backend, kind, omega):
             outs.append(np.stack([p.download(0, _lib.SLOT_V, q) for q in range(k)]))
             p.close()
         assert rel_err(outs[0], outs[1]) < 1e-12, (op.g, lowest, k)
-
-
-@pytest.mark.parametrize("g", [256, 512])
-def test_wide_windows_equal_narrow_windows(backend, g):
-    """MGCMT_OPT_WIDE: the 256-column (four columns per lane) Jacobi passes of the 5-point level do the arithmetic of
-    the 128-column ones — bit-identical cycles, with and without recompute, several chunk lengths, k vectors."""
-    op = laplacian_operator(g, "2d") * SCALE
-    rng = np.random.RandomState(12)
-    k = 2
-    v0, f = rng.rand(k, g * g), rng.rand(k, g * g)
-    try:
-        for nu1, nu2, rec, rows in ((2, 2, 2, 0), (1, 2, 2, 0), (2, 1, 0, 38), (3, 3, 2, 10), (1, 1, 1, 0)):
-            outs = []
-            for wide in (2, 0):
-                p = Plan(op, 8, nvec=k)
-                p.set_option(_lib.OPT_WIDE, wide)
-                p.set_option(_lib.OPT_RECOMPUTE, rec)
-                p.set_option(_lib.OPT_FUSED_ROWS, rows)
-                p.set_shifts([0.3, 0.9])
-                for q in range(k):
-                    p.upload(0, _lib.SLOT_V, q, v0[q])
-                    p.upload(0, _lib.SLOT_F, q, f[q])
-                for _ in range(2):
-                    p.vcycle(nu1, nu2, _lib.WJACOBI, omega=2. / 3., k=k, nu_coarse=2)
-                p.smooth(0, _lib.WJACOBI, 3, 2. / 3., k=k)                  # plain passes of 2 + 1 sweeps
-                outs.append(np.stack([p.download(0, _lib.SLOT_V, q) for q in range(k)]))
-                p.close()
-            assert np.array_equal(outs[0], outs[1]), (nu1, nu2, rec, rows)
-    finally:
-        p = Plan(laplacian_operator(16, "2d"), 8, nvec=1)
-        p.set_option(_lib.OPT_WIDE, 0)                                       # the default
-        p.set_option(_lib.OPT_FUSED_ROWS, 0)
-        p.close()
