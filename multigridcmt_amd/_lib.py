@@ -22,6 +22,7 @@ ABI_VERSION = 2
 OPT_FUSED = 0
 OPT_FUSED_ROWS = 1
 OPT_TAIL = 4
+OPT_LEX_WAVE = 5
 OPT_GRAPH = 2
 OPT_RECOMPUTE = 3
 

@@ -61,6 +61,14 @@ void launch_prolong(hipStream_t s, KGrid fine, KGrid coarse, KVec e, KVec v, int
 void launch_lex_sweep(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta,
                       double wU, double wL, int k);
 
+// the same sweep as a pipeline of waves over the whole chip (kernels_lexwave.hip; constant-coefficient operators on
+// grids of at least 128 columns).  carry: k * lex_wave_blocks(g) * g.nr * 2 doubles; sync: 2 + k * blocks words; sync[1]
+// != 0 after the sweep: a block gave up waiting (reported by the next synchronising call)
+bool lex_wave_supported(const KGrid& g, const KOp& op);
+long lex_wave_blocks(const KGrid& g);
+void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta, double wU,
+                     double wL, int k, double* carry, unsigned* sync);
+
 // fused row-streaming passes (fused_kernel.h, kernels_fused*.hip): vin -> vout with nsweep sweeps of weighted
 // Jacobi or multicolour Gauss-Seidel.  mode & 3: 0 plain, 1 prolong+correct first (coarse = correction), 2
 // residual+restrict last (coarse = right-hand side); mode & 4: vin is zero; mode & 8: vout is not written (mode 2);

@@ -274,6 +274,45 @@ int pass_sweeps(const mgcmt_plan* p, int l, int kind, int left) {
 }  // namespace mgcmt
 namespace {
 
+// one generalised lexicographic sweep on vector slot `slot` (right-hand side: slot F): the wave pipeline where it
+// covers the level, the one-workgroup kernel otherwise
+int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double wU, double wL, int k, hipStream_t s) {
+  const KGrid g = p->kgrid(l);
+  const KOp& op = p->levels[l].dA.k;
+  if (p->use_lex_wave && p->levels[l].nr == p->levels[l].gr && lex_wave_supported(g, op)) {
+    const size_t blocks = (size_t)lex_wave_blocks(g);
+    const size_t need_carry = (size_t)p->nvec * blocks * g.nr * 2, need_sync = 2 + (size_t)p->nvec * blocks;
+    if (need_carry > p->lex_carry_doubles || need_sync > p->lex_sync_words) {
+      MG_HIP(hipStreamSynchronize(s));
+      if (p->lex_carry) (void)hipFree(p->lex_carry);
+      if (p->lex_sync) (void)hipFree(p->lex_sync);
+      p->lex_carry = nullptr;
+      p->lex_sync = nullptr;
+      p->lex_carry_doubles = p->lex_sync_words = 0;
+      if (hipMalloc((void**)&p->lex_carry, need_carry * sizeof(double)) != hipSuccess ||
+          hipMalloc((void**)&p->lex_sync, need_sync * sizeof(unsigned)) != hipSuccess)
+        return fail(MGCMT_ERR_NOMEM, "scratch of the lexicographic wave pipeline");
+      p->lex_carry_doubles = need_carry;
+      p->lex_sync_words = need_sync;
+    }
+    launch_lex_wave(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync);
+    p->lex_wave_used = true;
+    return MGCMT_OK;
+  }
+  launch_lex_sweep(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k);
+  return MGCMT_OK;
+}
+
+// a synchronising call looks at the error word of the wave pipeline (a block that gave up waiting)
+int lex_wave_check(mgcmt_plan* p) {
+  if (!p->lex_wave_used || !p->lex_sync) return MGCMT_OK;
+  p->lex_wave_used = false;
+  unsigned err = 0;
+  MG_HIP(hipMemcpy(&err, p->lex_sync + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (err != 0) return fail(MGCMT_ERR_HIP, "lexicographic wave pipeline: a block timed out waiting for its neighbour");
+  return MGCMT_OK;
+}
+
 int smooth_impl(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hipStream_t s) {
   Level& L = p->levels[l];
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
@@ -308,16 +347,15 @@ int smooth_impl(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hip
     case MGCMT_GS_LEX:
     case MGCMT_SOR_LEX: {
       if (kind == MGCMT_GS_LEX || omega == 1.0) {
-        for (int it = 0; it < nu; ++it)
-          launch_lex_sweep(s, g, op, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, 0.0, 1.0, 1.0, 1.0, k);
+        for (int it = 0; it < nu; ++it) MG_TRY(lex_sweep(p, l, MGCMT_SLOT_V, 0.0, 1.0, 1.0, 1.0, k, s));
       } else {
         // reference SOR (MGCMTSolver.py:229-246): v <- (D-wL)^-1((1-w)D + wU) v + w (D-L)^-1 f.
         // T <- (D-L)^-1 f once, then per sweep the homogeneous recurrence followed by v += w T.
         MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
         for (int q = 0; q < k; ++q) launch_fill(s, p->kvec(l, MGCMT_SLOT_T, q).p, p->interior(l), 0.0);
-        launch_lex_sweep(s, g, op, p->kvec(l, MGCMT_SLOT_T), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, 0.0, 1.0, 0.0, 1.0, k);
+        MG_TRY(lex_sweep(p, l, MGCMT_SLOT_T, 0.0, 1.0, 0.0, 1.0, k, s));
         for (int it = 0; it < nu; ++it) {
-          launch_lex_sweep(s, g, op, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, 1.0 - omega, 0.0, omega, omega, k);
+          MG_TRY(lex_sweep(p, l, MGCMT_SLOT_V, 1.0 - omega, 0.0, omega, omega, k, s));
           for (int q = 0; q < k; ++q) launch_axpy(s, p->interior(l), omega, p->kvec(l, MGCMT_SLOT_T, q).p, p->kvec(l, MGCMT_SLOT_V, q).p);
         }
       }
@@ -736,6 +774,8 @@ int mgcmt_plan_destroy(mgcmt_plan* p) {
   for (auto& g : p->graphs)
     if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
   if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
+  if (p->lex_carry) (void)hipFree(p->lex_carry);
+  if (p->lex_sync) (void)hipFree(p->lex_sync);
   if (p->d_shifts) (void)hipFree(p->d_shifts);
   if (p->d_zero) (void)hipFree(p->d_zero);
   if (p->d_partials) (void)hipFree(p->d_partials);
@@ -807,7 +847,7 @@ int mgcmt_download(mgcmt_plan* p, int l, int slot, int vec, double* host, int64_
   MG_TRY(ensure_slot(p, l, slot));
   MG_HIP(hipMemcpyAsync(host, p->kvec(l, slot, vec).p, sizeof(double) * count, hipMemcpyDeviceToHost, S(stream)));
   MG_HIP(hipStreamSynchronize(S(stream)));
-  return MGCMT_OK;
+  return lex_wave_check(p);
 }
 
 int mgcmt_fill(mgcmt_plan* p, int l, int slot, int vec, double value, void* stream) {
@@ -1109,6 +1149,11 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
   }
   if (option == MGCMT_OPT_GRAPH) {
     p->use_graph = value != 0;
+    return MGCMT_OK;
+  }
+  if (option == MGCMT_OPT_LEX_WAVE) {
+    p->use_lex_wave = value != 0;
+    p->graphs_invalidate();
     return MGCMT_OK;
   }
   if (option == MGCMT_OPT_TAIL) {

@@ -79,6 +79,11 @@ struct mgcmt_plan {
   bool use_graph = true;
   long fused_rows = 0;            // tuning: rows per wave chunk of the fused passes, 0 = automatic
   mgcmt::ShardComm* comm = nullptr;  // communicator of a sharded plan (sharded.hip), owned
+  bool use_lex_wave = true;       // lexicographic sweeps as a pipeline of waves where kernels_lexwave.hip covers the level
+  double* lex_carry = nullptr;    // its scratch (grown on demand)
+  unsigned* lex_sync = nullptr;
+  size_t lex_carry_doubles = 0, lex_sync_words = 0;
+  bool lex_wave_used = false;     // the error word of lex_sync has not been looked at since the last sweep
   hipStream_t capture_stream = nullptr;
   struct CycleGraph {
     hipGraphExec_t exec = nullptr;

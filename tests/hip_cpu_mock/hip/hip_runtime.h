@@ -111,6 +111,8 @@ inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, 
   hipmock::run_grid(grid, block, [=]() { kernel(args...); });
 }
 
+inline unsigned atomicAdd(unsigned* p, unsigned x) { const unsigned old = *p; *p = old + x; return old; }  // one fiber runs at a time
+
 hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
