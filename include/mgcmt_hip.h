@@ -138,6 +138,12 @@ int mgcmt_axpy(mgcmt_plan* plan, int level, double alpha, int x_slot, int x_vec,
  * symmetric nv x nv Gram matrix, row-major.  The Rayleigh-Ritz steps of rqmin (MGCMTSolver.py:44-50: the entries of
  * its 2x2 matrices R and RM) and of the eigen-drivers need such sets; synchronises like mgcmt_dot. */
 int mgcmt_gram(mgcmt_plan* plan, int level, int nv, const int* slots, const int* vecs, double* host_out, void* stream);
+/* For the columns q < k of `slot`: rq_out[q] = <v_q, A v_q> / <v_q, v_q> and res_out[q] = ||(A - mu_q I) v_q||_2 with the
+ * plan's current shifts mu — the two numbers the reference's eigen-drivers print per column and iteration
+ * (2DPotMatrixVcycle.py:100-105: np.dot(v, hamiltonian.dot(v)) and np.linalg.norm(shifted_matrix.dot(v))).  One
+ * k-column operator application (into slot W) and one reduction pass per column; ONE synchronisation for all of them.
+ * Either output may be NULL. */
+int mgcmt_rayleigh_residual(mgcmt_plan* plan, int level, int slot, int k, double* rq_out, double* res_out, void* stream);
 /* dst = sum_t coeffs[t] * (slots[t], vecs[t]), 1 <= nterms <= 4; dst may be one of the inputs (the updates
  * x <- x + delta p, MGCMTSolver.py:52, and the residual A x - rho M x, :22-23, in one pass each) */
 int mgcmt_lincomb(mgcmt_plan* plan, int level, int nterms, const double* coeffs, const int* slots, const int* vecs, int dst_slot,

@@ -284,7 +284,8 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
     const size_t need_carry = (size_t)p->nvec * blocks * g.nr * 2, need_sync = 2 + (size_t)p->nvec * blocks;
     if (need_carry > p->lex_carry_doubles || need_sync > p->lex_sync_words) {
       MG_HIP(hipStreamSynchronize(s));
-      if (p->lex_carry) (void)hipFree(p->lex_carry);
+      if (p->d_rq) (void)hipFree(p->d_rq);
+  if (p->lex_carry) (void)hipFree(p->lex_carry);
       if (p->lex_sync) (void)hipFree(p->lex_sync);
       p->lex_carry = nullptr;
       p->lex_sync = nullptr;
@@ -774,6 +775,7 @@ int mgcmt_plan_destroy(mgcmt_plan* p) {
   for (auto& g : p->graphs)
     if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
   if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
+  if (p->d_rq) (void)hipFree(p->d_rq);
   if (p->lex_carry) (void)hipFree(p->lex_carry);
   if (p->lex_sync) (void)hipFree(p->lex_sync);
   if (p->d_shifts) (void)hipFree(p->d_shifts);
@@ -836,17 +838,14 @@ int mgcmt_upload(mgcmt_plan* p, int l, int slot, int vec, const double* host, in
   MG_TRY(check_vec(p, l, slot, vec));
   if (!host || count != p->interior(l)) return fail(MGCMT_ERR_INVALID, "upload: count must equal rows*cols of the level");
   MG_TRY(ensure_slot(p, l, slot));
-  MG_HIP(hipMemcpyAsync(p->kvec(l, slot, vec).p, host, sizeof(double) * count, hipMemcpyHostToDevice, S(stream)));
-  MG_HIP(hipStreamSynchronize(S(stream)));
-  return MGCMT_OK;
+  return transfer(p->device, true, p->kvec(l, slot, vec).p, const_cast<double*>(host), sizeof(double) * count, S(stream));
 }
 
 int mgcmt_download(mgcmt_plan* p, int l, int slot, int vec, double* host, int64_t count, void* stream) {
   MG_TRY(check_vec(p, l, slot, vec));
   if (!host || count != p->interior(l)) return fail(MGCMT_ERR_INVALID, "download: count must equal rows*cols of the level");
   MG_TRY(ensure_slot(p, l, slot));
-  MG_HIP(hipMemcpyAsync(host, p->kvec(l, slot, vec).p, sizeof(double) * count, hipMemcpyDeviceToHost, S(stream)));
-  MG_HIP(hipStreamSynchronize(S(stream)));
+  MG_TRY(transfer(p->device, false, p->kvec(l, slot, vec).p, host, sizeof(double) * count, S(stream)));
   return lex_wave_check(p);
 }
 
@@ -1046,6 +1045,35 @@ int mgcmt_gram(mgcmt_plan* p, int l, int nv, const int* slots, const int* vecs, 
   for (int a = 0; a < kGramMaxVectors; ++a)
     for (int b = a; b < kGramMaxVectors; ++b, ++t)
       if (b < nv) host_out[a * nv + b] = host_out[b * nv + a] = packed[t];
+  return MGCMT_OK;
+}
+
+int mgcmt_rayleigh_residual(mgcmt_plan* p, int l, int slot, int k, double* rq_out, double* res_out, void* stream) {
+  MG_TRY(check_vec(p, l, slot, 0));
+  MG_TRY(check_k(p, k));
+  if (slot == MGCMT_SLOT_W) return fail(MGCMT_ERR_INVALID, "rayleigh_residual uses slot W as its scratch");
+  if (!rq_out && !res_out) return fail(MGCMT_ERR_INVALID, "null outputs");
+  MG_TRY(ensure_slot(p, l, slot));
+  MG_TRY(ensure_slot(p, l, MGCMT_SLOT_W));
+  constexpr int kPairs = kGramMaxVectors * (kGramMaxVectors + 1) / 2;
+  if (!p->d_rq) MG_HIP(hipMalloc((void**)&p->d_rq, sizeof(double) * kPairs * kMaxVec));
+  hipStream_t s = S(stream);
+  // W_q = (A - mu_q I) v_q for all columns in one launch, then per column <v,v>, <v,r>, <r,r> in one pass each; the
+  // host sees all of them after ONE synchronisation
+  launch_apply(s, p->kgrid(l), p->levels[l].dA.k, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_W), p->d_shifts, k);
+  for (int q = 0; q < k; ++q) {
+    const double* v[kGramMaxVectors] = {p->kvec(l, slot, q).p, p->kvec(l, MGCMT_SLOT_W, q).p};
+    launch_gram(s, p->interior(l), v, 2, p->d_partials, p->d_rq + (long)q * kPairs);
+  }
+  MG_TRY(post_launch());
+  std::vector<double> packed((size_t)kPairs * k);
+  MG_HIP(hipMemcpyAsync(packed.data(), p->d_rq, sizeof(double) * kPairs * k, hipMemcpyDeviceToHost, s));
+  MG_HIP(hipStreamSynchronize(s));
+  for (int q = 0; q < k; ++q) {
+    const double vv = packed[(size_t)q * kPairs + 0], vr = packed[(size_t)q * kPairs + 1], rr = packed[(size_t)q * kPairs + kGramMaxVectors];
+    if (rq_out) rq_out[q] = p->h_shifts[q] + vr / vv;
+    if (res_out) res_out[q] = std::sqrt(rr);
+  }
   return MGCMT_OK;
 }
 

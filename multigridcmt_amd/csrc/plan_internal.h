@@ -67,6 +67,7 @@ struct mgcmt_plan {
   double* d_zero = nullptr;     // [kMaxVec] zeros (apply without shift)
   double* d_partials = nullptr; // reduction scratch
   double* d_scalars = nullptr;  // [4*kMaxVec] reduction results
+  double* d_rq = nullptr;       // Gram results of mgcmt_rayleigh_residual, one block per column
   std::vector<double> h_shifts;
   bool has_mass = false;
   bool use_fused = true;
@@ -125,6 +126,8 @@ int pass_sweeps(const mgcmt_plan* p, int l, int kind, int left);
 int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, hipStream_t s, int npre = 0,
                long out_lo = 0, long out_hi = -1, bool swap = true);
 void comm_release(mgcmt_plan* p);  // sharded.hip: frees p->comm
+// transfer.hip: a whole vector between caller memory and the device through the pinned ring; completed on return
+int transfer(int device, bool upload, void* dev, void* host, size_t bytes, hipStream_t stream);
 }  // namespace mgcmt
 
 #define MG_HIP(expr)                                                                                    \

@@ -94,6 +94,8 @@ def shift_invert_eigenpairs_resident(dimension="2d", gridsize=2 ** 10, bad_grids
         bad_eigenvalues, bad_eigenvectors = guesses
     bad_eigenvalues, bad_eigenvectors = np.asarray(bad_eigenvalues, dtype=float), np.array(bad_eigenvectors, dtype=float)
     kind, omega = solver._resolve_smoother(smoother)
+    if kind is None:
+        raise NotImplementedError("the device-resident loop takes MGCMTSolver's own smoothers; use shift_invert_eigenpairs for a callable")
     V, F, W = _lib.SLOT_V, _lib.SLOT_F, _lib.SLOT_W
     plan = Plan(laplacian_operator(g, dimension) * (-1 / np.pi ** 2), lowest_level, nvec=k)
     try:

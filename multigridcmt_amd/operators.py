@@ -213,6 +213,9 @@ def recognise(A, dimension=None):
         return A
     if not sp.issparse(A):
         A = sp.csr_matrix(np.asarray(A, dtype=np.float64))
+    tagged = getattr(A, "_mgcmt_structured", None)
+    if tagged is not None and tagged[1] == _digest(A) and (dimension is None or tagged[0].dimension == dimension):
+        return tagged[0]                      # a matrix this package assembled itself (e.g. a Galerkin level handed to a smoother)
     key = _cache_key(A)
     hit = _CACHE.get(key)
     if hit is not None and hit[0] is A and (dimension is None or hit[1].dimension == dimension):
@@ -284,3 +287,11 @@ def recognise(A, dimension=None):
         _CACHE.clear()
     _CACHE[key] = (A, op)
     return op
+
+
+def tag_structured(matrix, op):
+    """Remember on a scipy matrix assembled from `op` what it was assembled from (with a content digest, so a matrix
+    changed afterwards is not mistaken for it): ``recognise`` then maps it back without the structural check, also for
+    the 9-point Galerkin operators that check does not cover."""
+    matrix._mgcmt_structured = (op, _digest(matrix))
+    return matrix

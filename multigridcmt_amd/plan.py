@@ -166,6 +166,13 @@ class Plan:
         check(_lib.lib().mgcmt_gram(self._h, level, nv, slots, vecs, _lib.as_dp(out), stream))
         return out
 
+    def rayleigh_residual(self, level, slot, k, stream=None):
+        """(rq, res): Rayleigh quotients <v, A v>/<v, v> and residual norms ||(A - mu I) v|| of columns 0..k-1 of `slot`
+        (mu = the plan's shifts); one synchronisation for all columns.  Slot W is the scratch."""
+        rq, res = np.zeros(k), np.zeros(k)
+        check(_lib.lib().mgcmt_rayleigh_residual(self._h, level, slot, k, as_dp(rq), as_dp(res), stream))
+        return rq, res
+
     def lincomb(self, level, terms, dst, stream=None):
         """dst <- sum of coeff * (slot, vec) over `terms` = [(coeff, (slot, vec)), ...] (at most four)."""
         nt = len(terms)

@@ -14,7 +14,7 @@ import scipy.linalg
 
 from . import _lib
 from ._lib import GS_LEX, GS_MC, OP_A, OP_M, SLOT_F, SLOT_T, SLOT_V, SLOT_W, SOR_LEX, WJACOBI
-from .operators import StructuredOperator, laplacian_operator, recognise
+from .operators import StructuredOperator, laplacian_operator, recognise, tag_structured
 from .plan import get_plan
 from .processor import MGCMTProcessor
 from .stencil_maker import MGCMTStencilMaker
@@ -84,6 +84,8 @@ class MGCMTSolver:
     def smooth(self, v0, f, A, nu=4, smoother=None, dimension=None):
         """Addition (named by the build's north star): dispatch on a smoother callable."""
         kind, omega = self._resolve_smoother(smoother)
+        if kind is None:                       # a foreign callable: it is the smoother
+            return omega(v0, f, A, nu=nu)
         return self._smooth(v0, f, A, kind, nu, omega, dimension=dimension)
 
     def _resolve_smoother(self, smoother):
@@ -102,9 +104,82 @@ class MGCMTSolver:
                 return SOR_LEX, float(kw.get("omega", 1))
             if name == "gseidel_rb":
                 return GS_MC, float(kw.get("omega", 1.0))
-        raise NotImplementedError(
-            "smoother= must be one of this class's wjacobi / gseidel / sor / gseidel_rb (optionally wrapped in "
-            "functools.partial to set omega); arbitrary Python callables cannot run inside the device V-cycle")
+        if callable(smoother):
+            return None, smoother                  # seam 1 (MGCMTSolver.py:313,326): a foreign callable, run on host arrays
+        raise TypeError("smoother= must be callable as smoother(v0, f, shifted_matrix, nu=...)")
+
+    # -- the reference's two injection seams ---------------------------------------------------------
+    _checked_stencil_makers = {}
+
+    def _check_stencil_maker(self, stencil_maker, dimension):
+        """Seam 2 (MGCMTSolver.py:310-311): the cycle's grid transfers are the kernels' built-in full weighting and
+        (bi)linear interpolation — the matrices of MGCMTStencilMaker.py:27-78.  A caller's own stencil maker is accepted
+        when its matrices ARE those (checked once per class on a small grid); anything else raises instead of being
+        silently replaced."""
+        if stencil_maker is None or isinstance(stencil_maker, MGCMTStencilMaker):
+            return
+        key = (type(stencil_maker), dimension)
+        ok = self._checked_stencil_makers.get(key)
+        if ok is None:
+            own = self.stencil_maker
+            try:
+                ok = True
+                for coarse, fine in ((4, 8), (8, 16)):
+                    R, P = stencil_maker.restriction(fine, coarse, dimension=dimension), stencil_maker.interpolation(coarse, fine, dimension=dimension)
+                    R0, P0 = own.restriction(fine, coarse, dimension=dimension), own.interpolation(coarse, fine, dimension=dimension)
+                    for got, want in ((R, R0), (P, P0)):
+                        got = got.toarray() if hasattr(got, "toarray") else np.asarray(got)
+                        ok = ok and got.shape == want.shape and np.abs(got - want.toarray()).max() <= 1e-14
+            except Exception:
+                ok = False
+            self._checked_stencil_makers[key] = ok
+        if not ok:
+            raise ValueError(
+                "stencil_maker=%r builds restriction / interpolation matrices that differ from full weighting / (bi)linear "
+                "interpolation (MGCMTStencilMaker.py:27-78); the HIP V-cycle has exactly those transfers built in and will "
+                "not silently substitute them" % (stencil_maker,))
+
+    def _level_matrix(self, plan, level, shift):
+        """(A_level - shift I) as the scipy.sparse matrix the reference hands to a smoother (:287-288,313); A_level is
+        the Galerkin operator R*A*P of that level (:318), rebuilt from the plan's Kronecker factors."""
+        xf = plan.factors(level, 0) if plan.dim == 2 else None
+        yf = plan.factors(level, 1)
+        terms = [((xf[m].copy() if xf is not None else None), yf[m].copy()) for m in range(yf.shape[0])]
+        op = StructuredOperator("2d" if plan.dim == 2 else "1d", plan.g >> level, terms)
+        if shift:
+            op = op.shifted(float(shift))
+        return tag_structured(op.tocsr(), op)      # this class's own smoothers map it straight back (9-point levels too)
+
+    def _cycle_with_host_smoother(self, plan, smoother, nu1, nu2, nu_coarse, k, shifts, gram_schmidt, positional_nu=False):
+        """The cycle of vcycle / vcycle_matrix with a FOREIGN smoother callable: residual, restriction, coarse solve,
+        interpolation + correction and Gram-Schmidt stay on the device; on every level the iterate and the right-hand
+        side visit the host, where the caller's function is applied exactly as the reference applies it —
+        ``smoother(v, f, shifted_matrix, nu=nu)`` with (n, 1) arrays and the level's sparse matrix (:313,326,416,432)."""
+        last = plan.num_levels - 1
+        mats = {}
+
+        def smooth(level, nu):
+            n = plan.size(level)
+            for q in range(k):
+                key = (level, float(shifts[q]))
+                if key not in mats:
+                    mats[key] = self._level_matrix(plan, level, shifts[q])
+                v = plan.download(level, SLOT_V, q).reshape(n, 1)
+                f = plan.download(level, SLOT_F, q).reshape(n, 1)
+                out = np.asarray(smoother(v, f, mats[key], nu) if positional_nu else smoother(v, f, mats[key], nu=nu), dtype=np.float64)
+                if out.size != n:
+                    raise ValueError("smoother returned %r values for a level of %d" % (out.shape, n))
+                plan.upload(level, SLOT_V, q, out.reshape(-1))
+
+        for l in range(last):
+            smooth(l, nu1 if l == 0 else nu_coarse)
+            plan.residual_restrict(l, k=k)              # F[l+1] = R (F - (A - mu) V), V[l+1] = 0   (:315-316)
+        plan.coarse_solve(last, k=k)
+        for l in range(last - 1, -1, -1):
+            plan.prolong_correct(l, k=k)                # V += P V[l+1]                              (:323-324)
+            smooth(l, nu2 if l == 0 else nu_coarse)
+            if gram_schmidt:
+                plan.gramschmidt(l, SLOT_V, k, modified=1)
 
     # ------------------------------------------------------------------------------------------
     # cycles
@@ -137,10 +212,13 @@ class MGCMTSolver:
         the Galerkin operator is built from the unshifted A and the shift re-applied as -shift*I on
         every level (:287-288,318); the result is 1-D (:329) except when the start grid already is the
         lowest level, where it is (n, 1) (:305-308); bad sizes print and return None (:303-304).
-        ``stencil_maker`` is accepted for signature compatibility: the transfer operators are the
-        kernels' built-in full weighting / (bi)linear interpolation (MGCMTStencilMaker.py:27-78).
+        ``stencil_maker``: the transfer operators are the kernels' built-in full weighting / (bi)linear interpolation
+        (MGCMTStencilMaker.py:27-78); an object whose matrices differ raises (``_check_stencil_maker``).
+        ``smoother``: one of this class's methods runs inside the device cycle; any other callable is applied on host
+        arrays level by level with the transfers on the device (``_cycle_with_host_smoother``).
         """
         kind, omega = self._resolve_smoother(smoother)
+        self._check_stencil_maker(stencil_maker, dimension)
         n = len(v0)
         g = self._grid(n, dimension)
         _force_column(f, n)
@@ -153,7 +231,10 @@ class MGCMTSolver:
         plan.set_shifts([float(shift)])
         plan.upload(0, SLOT_V, 0, np.asarray(v0, dtype=np.float64).reshape(-1))
         plan.upload(0, SLOT_F, 0, np.asarray(f, dtype=np.float64).reshape(-1))
-        plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=1, nu_coarse=int(nu_coarse))
+        if kind is None:
+            self._cycle_with_host_smoother(plan, omega, int(nu1), int(nu2), int(nu_coarse), 1, [float(shift)], False)
+        else:
+            plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=1, nu_coarse=int(nu_coarse))
         v = plan.download(0, SLOT_V, 0)
         if g == lowest_level:
             return v.reshape(n, 1)
@@ -169,6 +250,9 @@ class MGCMTSolver:
         Galerkin operator of that level.  Returns the fine-grid solution; about 4/3 (2-D) of the work of one V-cycle
         per cycle and level.  Built from the same C-ABI calls as ``vcycle``."""
         kind, omega = self._resolve_smoother(smoother)
+        if kind is None:
+            raise NotImplementedError("fmg (an addition, not a reference function) takes this class's smoothers only")
+        self._check_stencil_maker(stencil_maker, dimension)
         n = len(f)
         g = self._grid(n, dimension)
         if not self._check_grid(g, lowest_level):
@@ -199,6 +283,7 @@ class MGCMTSolver:
         _force_column(v0, n)
         if not self._check_grid(g, 2):
             return None
+        self._check_stencil_maker(stencil_maker, dimension)
         g = int(g)
         if g < 4:
             raise ValueError("twogrid needs a fine grid of at least 4 points per direction")
@@ -207,7 +292,10 @@ class MGCMTSolver:
         plan.set_shifts([float(shift)])
         plan.upload(0, SLOT_V, 0, np.asarray(v0, dtype=np.float64).reshape(-1))
         plan.upload(0, SLOT_F, 0, np.asarray(f, dtype=np.float64).reshape(-1))
-        plan.twogrid(int(nu1), int(nu2), kind, omega=omega, k=1)
+        if kind is None:                       # the reference passes nu positionally here (:358,369)
+            self._cycle_with_host_smoother(plan, omega, int(nu1), int(nu2), 4, 1, [float(shift)], False, positional_nu=True)
+        else:
+            plan.twogrid(int(nu1), int(nu2), kind, omega=omega, k=1)
         return plan.download(0, SLOT_V, 0)
 
     def vcycle_matrix(self, v0_matrix, f_matrix, A, stencil_maker, nu1=4, nu2=4, smoother=None, shifts=None,
@@ -229,6 +317,7 @@ class MGCMTSolver:
         g = self._grid(n, dimension)
         if not self._check_grid(g, lowest_level):
             return None
+        self._check_stencil_maker(stencil_maker, dimension)
         op = recognise(A, dimension)
         plan = get_plan(op, int(lowest_level), nvec=k)
         plan.set_shifts(shifts)
@@ -239,7 +328,10 @@ class MGCMTSolver:
             else:
                 plan.upload(0, SLOT_V, i, v0_matrix[:, i])
             plan.upload(0, SLOT_F, i, f_matrix[:, i])
-        plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=k, nu_coarse=int(nu_coarse), gram_schmidt=True)
+        if kind is None:
+            self._cycle_with_host_smoother(plan, omega, int(nu1), int(nu2), int(nu_coarse), k, shifts, True)
+        else:
+            plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=k, nu_coarse=int(nu_coarse), gram_schmidt=True)
         # columns are downloaded as contiguous rows of a (k, n) array; the (n, k) result is its transpose (a
         # column-major array: the same values and indexing as the reference's, without k strided scatters on the host)
         rows = np.empty((k, n))

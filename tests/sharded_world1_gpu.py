@@ -53,33 +53,50 @@ for transport in ("rccl", "torch"):
     sp.upload_local(_lib.SLOT_F, f)
     sp.fill_local(_lib.SLOT_V, 0.0)
     if transport == "rccl":
-        # 1. ring self-exchange on levels 0 and 1 of F (level 1 of a 4096^2 / 1024 plan is a strip level too)
-        sp.plan.upload(1, _lib.SLOT_F, 0, np.arange((g // 2) ** 2, dtype=np.float64))
-        sp.exchange_halo((0, _lib.SLOT_F), ring=True)
-        sp.exchange_halo((1, _lib.SLOT_F), ring=True)
+        # 1. ring self-exchange on levels 0 and 1 of the spare slot W (level 1 of a 4096^2 / 1024 plan is a strip level too)
+        W = _lib.SLOT_W
+        sp.plan.upload(0, W, 0, np.random.RandomState(3).rand(g * g))
+        sp.plan.upload(1, W, 0, np.arange((g // 2) ** 2, dtype=np.float64))
+        sp.exchange_halo((0, W), ring=True)
+        sp.exchange_halo((1, W), ring=True)
         sp.sync()
         for level, cols in ((0, g), (1, g // 2)):
             rows = cols
-            base = sp.plan.vec_ptr(level, _lib.SLOT_F, 0) - H * cols * 8
+            base = sp.plan.vec_ptr(level, W, 0) - H * cols * 8
             flat = torch.as_tensor(_DevicePointer(base, (rows + 2 * H) * cols), device="cuda:0").cpu().numpy().reshape(rows + 2 * H, cols)
             assert np.array_equal(flat[:H], flat[rows:rows + H]), "upper halo rows != bottom rows (level %d)" % level
             assert np.array_equal(flat[rows + H:], flat[H:2 * H]), "lower halo rows != top rows (level %d)" % level
         print("ring self-exchange through RCCL ok")
+        # 2. the cycle with the rank as its own neighbour: split launches, RCCL on the second stream, overlap — the rows
+        #    received land in halo rows the fused kernels of a whole-grid level never read, so the result is unchanged
         sp.set_comm_option(_lib.COMM_OPT_SELF_RING, 1)
+        for _ in range(2):
+            sp.vcycle(2, 2, _lib.GS_MC, omega=1.0, nu_coarse=2)
+        ring_result = sp.download_local(_lib.SLOT_V)
+        assert np.array_equal(ring_result, want), "self-ring cycle differs from the single plan"
+        for opt in (_lib.COMM_OPT_OVERLAP, _lib.COMM_OPT_SPLIT):          # overlap off / split off: the same numbers
+            sp.set_comm_option(opt, 0)
+            sp.fill_local(_lib.SLOT_V, 0.0)
+            for _ in range(2):
+                sp.vcycle(2, 2, _lib.GS_MC, omega=1.0, nu_coarse=2)
+            assert np.array_equal(sp.download_local(_lib.SLOT_V), want), opt
+        print("self-ring cycles (overlap / no overlap / no split) bit-equal to the single plan")
+        # back to the plain one-rank chain; the ring traffic left the neighbours' rows in halo rows that the Dirichlet
+        # kernels expect to be zero: clear them
+        sp.set_comm_option(_lib.COMM_OPT_SELF_RING, 0)
+        sp.set_comm_option(_lib.COMM_OPT_OVERLAP, 1)
+        sp.set_comm_option(_lib.COMM_OPT_SPLIT, 1)
+        for level in range(sp.strip_levels + 1):
+            for slot in (_lib.SLOT_V, _lib.SLOT_F, _lib.SLOT_T):
+                sp.plan.zero(level, slot, 0)
+        sp.upload_local(_lib.SLOT_F, f)
+        sp.fill_local(_lib.SLOT_V, 0.0)
     for _ in range(2):
         sp.vcycle(2, 2, _lib.GS_MC, omega=1.0, nu_coarse=2)
     got, res = sp.download_local(_lib.SLOT_V), sp.residual_norm()
     err = np.linalg.norm(got - want) / np.linalg.norm(want)
     print(transport, "rel err", err, "residual", res, want_res, "strip levels", sp.strip_levels)
     assert err < 1e-12 and abs(res - want_res) < 1e-9 * want_res
-    if transport == "rccl":
-        # overlap off / split off give the same numbers
-        for opt in (_lib.COMM_OPT_OVERLAP, _lib.COMM_OPT_SPLIT):
-            sp.set_comm_option(opt, 0)
-            sp.fill_local(_lib.SLOT_V, 0.0)
-            for _ in range(2):
-                sp.vcycle(2, 2, _lib.GS_MC, omega=1.0, nu_coarse=2)
-            assert np.array_equal(sp.download_local(_lib.SLOT_V), got), opt
     sp.close()
 dist.destroy_process_group()
 print("SHARDED_WORLD1_OK")

@@ -276,8 +276,70 @@ def test_shape_and_error_conventions(trio, capsys):
     assert "Length of start vector is not a power of 2" in capsys.readouterr().out
     assert solver.vcycle(np.ones(12), np.zeros(12), sm.laplacian(12), sm) is None
     assert "power of 2" in capsys.readouterr().out
-    with pytest.raises(NotImplementedError):
-        solver.vcycle(np.ones(8), np.zeros(8), A, sm, smoother=lambda v, f, A, nu=4: v)
+    with pytest.raises(TypeError):
+        solver.vcycle(np.ones(8), np.zeros(8), A, sm, smoother="gseidel")
+
+
+def test_seam_foreign_smoother_callable(trio):
+    """Seam 1 (MGCMTSolver.py:313,326,416,432): ANY callable smoother(v, f, shifted_matrix, nu=) is honoured — applied on
+    host arrays level by level, the transfers, the coarse solve and Gram-Schmidt on the device.  The fixtures below were
+    written by the reference's own vcycle with exactly these lambda wrappers (oracle/gen_golden.py:135,156)."""
+    solver, sm, _ = trio
+    gold = load_golden("vcycle_1d")
+    x = solver.vcycle(np.zeros(128), gold["h128_f"].copy(), H(sm, 128), sm, nu1=2, nu2=3,
+                      smoother=lambda v, f, A, nu=4: solver.sor(v, f, A, nu=nu, omega=1.3), shift=0.9, lowest_level=8)
+    assert x.shape == (128,) and rel_err(x, gold["h128_vcycle_sor_shift0.9_low8"]) < NORTH_STAR
+    g2 = load_golden("vcycle_2d")
+    x = solver.vcycle(np.zeros(256), g2["g16_f"].copy(), sm.laplacian(16, "2d"), sm, nu1=3, nu2=1,
+                      smoother=lambda v, f, A, nu=4: solver.sor(v, f, A, nu=nu, omega=1.2), dimension="2d", lowest_level=4)
+    assert rel_err(x, g2["lap16_sor1.2_low4"]) < NORTH_STAR
+    # a smoother that owes nothing to this package (NumPy damped Jacobi on the scipy matrix it is handed): the cycle
+    # must be the device cycle with the built-in wjacobi, also for k columns with Gram-Schmidt (vcycle_matrix)
+    calls = []
+
+    def numpy_jacobi(v, f, A, nu=4):
+        calls.append((A.shape[0], nu))
+        d = A.diagonal().reshape(-1, 1)
+        v = np.array(v, dtype=float).reshape(-1, 1)
+        for _ in range(nu):
+            v = v + (2. / 3.) * (np.asarray(f).reshape(-1, 1) - A @ v) / d
+        return v
+
+    A2, f2 = H(sm, 32, "2d"), np.random.RandomState(6).rand(1024)
+    a = solver.vcycle(np.zeros(1024), f2.copy(), A2, sm, nu1=2, nu2=1, smoother=numpy_jacobi, shift=1.1, dimension="2d", lowest_level=4)
+    b = solver.vcycle(np.zeros(1024), f2.copy(), A2, sm, nu1=2, nu2=1, shift=1.1, dimension="2d", lowest_level=4)
+    assert rel_err(a, b) < 1e-12
+    assert calls == [(1024, 2), (256, 4), (64, 4), (64, 4), (256, 4), (1024, 1)]      # nu not forwarded below the top (:320)
+    F = np.random.RandomState(7).rand(1024, 3)
+    shifts = np.array([0.0, 0.5, 1.5])
+    a = solver.vcycle_matrix(np.zeros((1024, 3)), F, A2, sm, shifts=shifts, smoother=numpy_jacobi, lowest_level=8, dimension="2d")
+    b = solver.vcycle_matrix(np.zeros((1024, 3)), F, A2, sm, shifts=shifts, lowest_level=8, dimension="2d")
+    assert rel_err(a, b) < 1e-11
+    t = solver.twogrid(np.zeros(64), np.ones(64), H(sm, 64), sm, smoother=numpy_jacobi, shift=0.2)
+    assert rel_err(t, solver.twogrid(np.zeros(64), np.ones(64), H(sm, 64), sm, shift=0.2)) < 1e-12
+
+
+def test_seam_foreign_stencil_maker(trio):
+    """Seam 2 (MGCMTSolver.py:310-311): a caller's stencil maker is accepted when its matrices are the built-in transfers
+    (here the oracle's independent restatement) and REFUSED when they are not (injection instead of full weighting)."""
+    from oracle.sparse_ref import RefStencilMaker
+    solver, sm, _ = trio
+    A, f = H(sm, 64), np.random.RandomState(1).rand(64)
+    want = solver.vcycle(np.zeros(64), f.copy(), A, sm, lowest_level=8)
+    assert np.array_equal(solver.vcycle(np.zeros(64), f.copy(), A, RefStencilMaker(), lowest_level=8), want)
+
+    class Injection(RefStencilMaker):
+        def restriction(self, old, new, dimension="1d"):
+            R = super().restriction(old, new, dimension=dimension).tolil()
+            R[:, :] = 0
+            for i in range(R.shape[0]):
+                R[i, 2 * i + 1] = 1.0
+            return R.tocsr()
+
+    with pytest.raises(ValueError, match="differ from full weighting"):
+        solver.vcycle(np.zeros(64), f.copy(), A, Injection(), lowest_level=8)
+    with pytest.raises(ValueError):
+        solver.vcycle_matrix(np.zeros((64, 2)), np.ones((64, 2)), A, Injection(), shifts=np.zeros(2), lowest_level=8)
 
 
 def test_nu_not_forwarded_to_coarse_levels(trio):
