@@ -13,10 +13,12 @@
 // shifts and broadcasts, no LDS); the carry-in (the left block's edge value) enters only at the end of the scan, so
 // waiting for it is off the critical path.
 //
-// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): edge values are stored as 8-byte agent-scope atomics
-// (write-through, sc1), every R rows the storing wave drains its stores (s_waitcnt vmcnt(0)) and one lane stores the
-// progress word (agent-scope atomic); the consumer polls that word (relaxed, bounded, with s_sleep) and reads the
-// edge values with agent-scope atomic loads (sc1: they bypass its CU's L1).  Block numbers are handed out by a
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, "the data is the flag"): the two edge values of a row
+// travel as four 8-byte granules {tag, half a double}, each written by ONE agent-scope atomic store (write-through,
+// sc1) into a buffer cleared before the launch; the consumer reads 16 rows of granules with one agent-scope atomic
+// load per lane (sc1: it bypasses its CU's L1) and takes the rows whose four tags are set — no flag, no fence, no
+// drain of the producer's memory pipeline; the load is issued a row ahead of its use, so a consumer that runs a few
+// rows behind its producer never waits.  Block numbers are handed out by a
 // ticket counter, so a block only ever waits for one that has already started; every spin is bounded by a timeout
 // that raises an error word instead of hanging the GPU.
 //
@@ -28,58 +30,52 @@ namespace mgcmt {
 
 namespace {
 
-#ifndef MGCMT_LEXWAVE_PUBLISH
-#define MGCMT_LEXWAVE_PUBLISH 8  // rows between two publications of a block's progress
-#endif
-constexpr int kPublish = MGCMT_LEXWAVE_PUBLISH;
-constexpr int kDepth = 3;  // rows of old values in flight ahead of the row being processed
+constexpr int kDepth = 3;   // rows of old values in flight ahead of the row being processed
+constexpr int kBatch = 16;  // rows of the left block's edge records fetched by one load instruction (4 granules each)
 
 struct LexWaveArgs {
   double* v;
   const double* f;
   long vstride;
   int nr, nc, nblocks;
+  int five;                          // constant 5-point operator: no corner terms, no special last row / column
   double c[3][3];                    // interior coefficients [di + 1][dj + 1]
   double crow[3], ccol[3], ccorner;  // last row: own-row coefficients (W, C, E); last column: centre column (N, C, S)
   const double* shifts;
   double alpha, beta, wU, wL;
-  double* carry;       // [vector][block][row][2]: new values of the block's lanes 63 and 62
-  unsigned* sync;      // [0] ticket, [1] error, [2 + vector*nblocks + block] rows completed
-  long carry_stride;   // doubles per vector
+  unsigned long long* carry;  // [vector][block][row][4] granules {tag = 1 : 32, half of a double : 32}: lanes 62 / 63's new values
+  unsigned* sync;             // [0] ticket, [1] error
+  long carry_stride;          // granules per vector
 };
+
+typedef unsigned long long u64;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const u64 u = __builtin_bit_cast(u64, v);
   const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
   const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  return __builtin_bit_cast(double, ((u64)hi << 32) | lo);
 }
 template <int D>
-__device__ __forceinline__ double row_shr(double v, int) { return dpp<0x110 + D>(v); }    // lane - D inside rows of 16
+__device__ __forceinline__ double row_shr(double v, int) { return dpp<0x110 + D>(v); }    // lane - D inside rows of 16 (else 0)
 __device__ __forceinline__ double bcast15(double v, int) { return dpp<0x142>(v); }         // lane 15 of the previous row of 16
 __device__ __forceinline__ double bcast31(double v, int) { return dpp<0x143>(v); }         // lane 31
 __device__ __forceinline__ double from_left(double v, int) { return dpp<0x138>(v); }       // lane - 1 (lane 0: 0)
 __device__ __forceinline__ double from_right(double v, int) { return dpp<0x130>(v); }      // lane + 1 (lane 63: 0)
-__device__ __forceinline__ double lane_value(double v, int k) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+__device__ __forceinline__ u64 lane_bits(u64 u, int k) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, k);
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), k);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  return ((u64)hi << 32) | lo;
 }
+__device__ __forceinline__ u64 vote(bool x) { return __ballot(x); }
 __device__ __forceinline__ unsigned load_word(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_word(unsigned* p, unsigned x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double load_shared(const double* p) {
-  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return __builtin_bit_cast(double, u);
-}
-__device__ __forceinline__ void store_shared(double* p, double x) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ unsigned long long now_ticks() { return wall_clock64(); }  // 100 MHz
-__device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(2); }
+__device__ __forceinline__ u64 load_granule(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_granule(u64* p, u64 x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 now_ticks() { return wall_clock64(); }  // 100 MHz
+__device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(1); }
 #else
 // host-side stand-ins (the emulator runs one workgroup at a time, in block order: a block never has to wait)
 template <int D>
@@ -88,18 +84,23 @@ __device__ __forceinline__ double bcast15(double v, int lane) { return __shfl(v,
 __device__ __forceinline__ double bcast31(double v, int) { return __shfl(v, 31); }
 __device__ __forceinline__ double from_left(double v, int lane) { const double r = __shfl_up(v, 1); return lane >= 1 ? r : 0.0; }
 __device__ __forceinline__ double from_right(double v, int lane) { const double r = __shfl_down(v, 1); return lane <= 62 ? r : 0.0; }
-__device__ __forceinline__ double lane_value(double v, int k) { return __shfl(v, k); }
+__device__ __forceinline__ u64 lane_bits(u64 u, int k) { return (u64)__shfl((long long)u, k); }
+__device__ __forceinline__ u64 vote(bool x) {
+  u64 m = 0;
+  for (int k = 0; k < 64; ++k) m |= (u64)(__shfl(x ? 1 : 0, k) & 1) << k;
+  return m;
+}
 __device__ __forceinline__ unsigned load_word(const unsigned* p) { return *p; }
 __device__ __forceinline__ void store_word(unsigned* p, unsigned x) { *p = x; }
-__device__ __forceinline__ double load_shared(const double* p) { return *p; }
-__device__ __forceinline__ void store_shared(double* p, double x) { *p = x; }
-__device__ __forceinline__ void drain_stores() {}
-__device__ __forceinline__ unsigned long long now_ticks() { return 0; }
+__device__ __forceinline__ u64 load_granule(const u64* p) { return *p; }
+__device__ __forceinline__ void store_granule(u64* p, u64 x) { *p = x; }
+__device__ __forceinline__ u64 now_ticks() { return 0; }
 __device__ __forceinline__ void nap() {}
 #endif
 
-constexpr unsigned long long kTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz counter: a stuck pipeline gives up
+constexpr u64 kTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz counter: a stuck pipeline gives up
 
+template <bool FIVE>
 __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   const int lane = threadIdx.x;
   // block number = order of arrival: whoever this block waits for has started before it
@@ -111,69 +112,74 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   const int nr = a.nr, nc = a.nc;
   double* __restrict__ v = a.v + (long)q * a.vstride;
   const double* __restrict__ f = a.f + (long)q * a.vstride;
-  double* my_carry = a.carry + (long)q * a.carry_stride + (long)J * nr * 2;
-  const double* left_carry = my_carry - (long)nr * 2;
-  unsigned* my_progress = a.sync + 2 + (long)q * a.nblocks + J;
-  const unsigned* left_progress = my_progress - 1;
+  u64* my_rec = a.carry + (long)q * a.carry_stride + (long)J * nr * 4;
+  const u64* left_rec = my_rec - (long)nr * 4;
 
   const int i0 = J * 64 - (nc - 1) > 0 ? J * 64 - (nc - 1) : 0;  // first row with a column of this block inside the grid
   const int i1 = J * 64 + 63 < nr - 1 ? J * 64 + 63 : nr - 1;    // last one
   const int left_last = J > 0 ? (J * 64 - 1 < nr - 1 ? J * 64 - 1 : nr - 1) : -1;  // last row the left block works on
   const bool publish = J + 1 < a.nblocks;
+  if (i0 > i1) return;  // (cannot happen for nblocks = ceil((nr + nc - 1) / 64); kept as a guard)
 
   const double mu = a.shifts[q];
   const double alpha = a.alpha, beta = a.beta, wU = a.wU, wL = a.wL;
   // coefficient classes: interior, last column, last row, corner
   const double cNW = a.c[0][0], cNE = a.c[0][2], cSW = a.c[2][0], cSE = a.c[2][2];
+  const double cN_int = a.c[0][1], cS_int = a.c[2][1], cW_int = a.c[1][0], cE_int = a.c[1][2];
   const double d_int = a.c[1][1] - mu, d_col = a.ccol[1] - mu, d_row = a.crow[1] - mu, d_cor = a.ccorner - mu;
   const double inv_int = 1.0 / d_int, inv_col = 1.0 / d_col, inv_row = 1.0 / d_row, inv_cor = 1.0 / d_cor;
+  const double ad_int = alpha * d_int;
+  // rows whose 64 columns are all interior points: the recurrence has ONE q, so only the p part of the maps is scanned;
+  // the products of q it needs are per-lane constants
+  const double q0 = -wL * cW_int * inv_int;
+  const double q2 = q0 * q0, q4 = q2 * q2, q8 = q4 * q4;
+  double qpow = q0, Q15 = 0.0, Q31 = 0.0;  // q0^(lane + 1); q0^((lane & 15) + 1) on the second 16 of every 32; q0^(lane - 31) on the upper 32
+  {
+    double acc = 1.0;
+    for (int m = 1; m <= 64; ++m) {
+      acc *= q0;  // q0^m
+      if ((lane & 16) && m == (lane & 15) + 1) Q15 = acc;
+      if (lane >= 32 && m == lane - 31) Q31 = acc;
+      if (m == lane + 1) qpow = acc;
+    }
+  }
 
-  // old values: window of row r = v[r][J*64 + lane - r] (this block's columns on that row) and, in lanes 0 and 1, the
-  // two columns to its right.  Rows nr.. are the zero halo rows; columns outside the grid read as zero.
+  // old values: window of row r = v[r][J*64 + lane - r] (this block's columns on that row); T = the two columns to its
+  // right, held by lanes 62 (first) and 63 (second), zero elsewhere.  Rows nr.. are the zero halo rows; columns outside
+  // the grid read as zero.
   auto load_window = [&](int r, double& w, double& t, double& fr) {
-    const int rr = r < nr ? r : nr;  // rows beyond the grid: the (zero) halo row
+    const int rr = r < nr ? r : nr;
     const int jw = J * 64 + lane - r;
-    const int jt = J * 64 + 64 + lane - r;
+    const int jt = jw + 2;  // lanes 62, 63: columns J*64 + 64 - r and + 65 - r
     const int jwc = jw < 0 ? 0 : (jw > nc - 1 ? nc - 1 : jw);
     const int jtc = jt < 0 ? 0 : (jt > nc - 1 ? nc - 1 : jt);
-    const double wv = v[(long)rr * nc + jwc];
-    const double tv = lane < 2 ? v[(long)rr * nc + jtc] : 0.0;
-    const double fv = f[(long)rr * nc + jwc];
+    const double* row = v + (long)rr * nc;
+    const double wv = row[jwc];
+    double tv = 0.0;
+    if (lane >= 62) tv = row[jtc];
+    fr = f[(long)rr * nc + jwc];
     w = (jw >= 0 && jw < nc) ? wv : 0.0;
-    t = (lane < 2 && jt >= 0 && jt < nc) ? tv : 0.0;
-    fr = fv;
+    t = (lane >= 62 && jt >= 0 && jt < nc) ? tv : 0.0;
   };
 
-  // edge values of the left block, 64 rows at a time: lane r holds row cbase + r
-  int cbase = 0, cvalid = 0;
-  double cb1 = 0.0, cb2 = 0.0;
-  bool failed = false;
-  auto fetch_carries = [&](int row) {
-    // wait until the left block has published `row`, then take what is there (up to 64 rows)
-    unsigned done = load_word(left_progress);
-    if (done < (unsigned)row + 1u) {
-      const unsigned long long t0 = now_ticks();
-      while (true) {
-        nap();
-        done = load_word(left_progress);
-        if (done >= (unsigned)row + 1u) break;
-        if (now_ticks() - t0 > kTimeoutTicks || load_word(a.sync + 1) != 0u) {
-          failed = true;
-          break;
-        }
-      }
-    }
-    int upto = (int)done < left_last + 1 ? (int)done : left_last + 1;  // rows [row, upto) are there
-    if (failed) upto = row;
+  // edge records of the left block: lane l holds granule (l & 3) of row cbase + (l >> 2); rows [cbase, cbase + cvalid)
+  // of the batch were complete when it was loaded
+  int cbase = -(1 << 30), cvalid = 0;
+  bool cchecked = true, failed = false;
+  u64 R = 0;
+  auto issue_batch = [&](int row) {  // no wait: the load is consumed by check_batch
     cbase = row;
-    cvalid = upto - row < 64 ? upto - row : 64;
-    const int r = row + lane;
-    const bool have = lane < cvalid;
-    const int rc = have ? r : row;
-    const double x1 = load_shared(left_carry + (long)rc * 2);
-    const double x2 = load_shared(left_carry + (long)rc * 2 + 1);
-    cb1 = have ? x1 : 0.0;
-    cb2 = have ? x2 : 0.0;
+    cchecked = false;
+    R = load_granule(left_rec + (long)row * 4 + lane);
+  };
+  auto check_batch = [&]() {
+    const u64 m = vote((unsigned)(R >> 32) == 1u);
+    const u64 full = m & (m >> 1) & (m >> 2) & (m >> 3) & 0x1111111111111111ull;
+    const u64 gap = ~full & 0x1111111111111111ull;
+    int n = gap ? (int)(__builtin_ctzll(gap) >> 2) : kBatch;
+    if (cbase + n > left_last + 1) n = left_last + 1 - cbase;  // (records beyond the left block's last row do not exist)
+    cvalid = n < 0 ? 0 : n;
+    cchecked = true;
   };
   auto carries_of = [&](int row, double& c1, double& c2) {
     if (J == 0 || row < 0 || row > left_last) {  // no left block there: Dirichlet zero
@@ -181,16 +187,35 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       c2 = 0.0;
       return;
     }
-    if (!(row >= cbase && row < cbase + cvalid)) fetch_carries(row);
-    const int k = row - cbase;
-    c1 = lane_value(cb1, k);
-    c2 = lane_value(cb2, k);
+    if (!cchecked) check_batch();
+    if (!(row >= cbase && row < cbase + cvalid)) {
+      u64 t0 = 0;
+      bool timing = false;
+      while (true) {
+        issue_batch(row);
+        check_batch();
+        if (cvalid > 0) break;
+        if (!timing) {
+          t0 = now_ticks();
+          timing = true;
+        }
+        nap();
+        if (now_ticks() - t0 > kTimeoutTicks || load_word(a.sync + 1) != 0u) {
+          failed = true;
+          break;
+        }
+      }
+      if (failed) {
+        c1 = 0.0;
+        c2 = 0.0;
+        return;
+      }
+    }
+    const int k = (row - cbase) * 4;
+    const u64 g0 = lane_bits(R, k), g1 = lane_bits(R, k + 1), g2 = lane_bits(R, k + 2), g3 = lane_bits(R, k + 3);
+    c2 = __builtin_bit_cast(double, (g0 & 0xffffffffull) | (g1 << 32));  // the left block's lane 62
+    c1 = __builtin_bit_cast(double, (g2 & 0xffffffffull) | (g3 << 32));  // ... lane 63
   };
-
-  if (i0 > i1) {  // nothing inside the grid (cannot happen for nblocks = ceil((nr + nc - 1) / 64); kept as a guard)
-    if (lane == 0) store_word(my_progress, (unsigned)nr);
-    return;
-  }
 
   // pipeline registers: rows i .. i + kDepth of old values
   double wn[kDepth + 1], tl[kDepth + 1], fr[kDepth + 1];
@@ -200,41 +225,30 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   double prev = 0.0;  // new values of the previous row (this lane's column + 1 there)
   double c1p, c2p;    // the left block's edge values on the previous row
   carries_of(i0 - 1, c1p, c2p);
-  int since_publish = 0;
+  // e(i) = old value right of this lane's column on row i = s(i - 1): carried from row to row
+  double e = from_right(wn[0], lane) + from_left(tl[0], lane);
 
   for (int i = i0; i <= i1; ++i) {
-    const int j = J * 64 + lane - i;
-    const bool valid = j >= 0 && j < nc;
-    const bool last_col = j == nc - 1, last_row = i == nr - 1;
+    const int jmin = J * 64 - i;  // lane 0's column
     // new values of row i-1: NE = this lane, N = lane - 1, NW = lane - 2 (the left block's edge beyond lane 0)
-    double n = from_left(prev, lane);
-    if (lane == 0) n = c1p;
-    double nw = from_left(n, lane);
-    if (lane == 0) nw = c2p;
+    const double n = from_left(prev, lane) + (lane == 0 ? c1p : 0.0);
     const double ne = prev;
-    // old values: own row (E = lane + 1) and the row below (SW = this lane of its window, S = lane + 1, SE = lane + 2)
+    // old values: own row, and the row below (SW = this lane of its window, S = lane + 1, SE = lane + 2)
     const double own = wn[0];
-    double e = from_right(wn[0], lane);
-    const double t00 = lane_value(tl[0], 0);
-    if (lane == 63) e = t00;
     const double sw = wn[1];
-    double s = from_right(wn[1], lane);
-    const double t10 = lane_value(tl[1], 0), t11 = lane_value(tl[1], 1);
-    if (lane == 63) s = t10;
-    double se = from_right(s, lane);
-    if (lane == 63) se = t11;
-    const double cN = last_col ? a.ccol[0] : a.c[0][1], cS = last_col ? a.ccol[2] : a.c[2][1];
-    const double cW = last_row ? a.crow[0] : a.c[1][0], cE = last_row ? a.crow[2] : a.c[1][2];
-    const double d = last_row ? (last_col ? d_cor : d_row) : (last_col ? d_col : d_int);
-    const double invd = last_row ? (last_col ? inv_cor : inv_row) : (last_col ? inv_col : inv_int);
-    const double lower = fma(cNW, nw, fma(cN, n, cNE * ne));
-    const double upper = fma(cE, e, fma(cSW, sw, fma(cS, s, cSE * se)));
-    double p = (alpha * d * own + beta * fr[0] - wU * upper - wL * lower) * invd;
-    double qq = -wL * cW * invd;
-    if (!valid) {
-      p = 0.0;
-      qq = 0.0;
+    const double s1 = from_right(wn[1], lane);
+    const double s = s1 + from_left(tl[1], lane);
+    double lower, upper;
+    if (FIVE) {
+      lower = cN_int * n;
+      upper = fma(cE_int, e, cS_int * s);
+    } else {
+      const double nw = from_left(n, lane) + (lane == 0 ? c2p : 0.0);
+      const double se = from_right(s1, lane) + tl[1];
+      lower = fma(cNW, nw, fma(cN_int, n, cNE * ne));
+      upper = fma(cE_int, e, fma(cSW, sw, fma(cS_int, s, cSE * se)));
     }
+    const double frow = fr[0];
     // refill the pipeline while the scan runs
 #pragma unroll
     for (int dd = 0; dd < kDepth; ++dd) {
@@ -243,8 +257,54 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       fr[dd] = fr[dd + 1];
     }
     load_window(i + kDepth + 1, wn[kDepth], tl[kDepth], fr[kDepth]);
-    // inclusive scan of the maps x -> p + q x over the lanes (`first` applied before `second`:
-    // p = second.p + second.q * first.p, q = second.q * first.q)
+    // the left block's edge values of this row: ask for them now if the batch at hand does not hold them
+    const bool left_here = J > 0 && i <= left_last;
+    if (left_here && cchecked && !(i >= cbase && i < cbase + cvalid)) issue_batch(i);
+
+    double x;
+    const bool interior = jmin >= 0 && (FIVE ? jmin + 63 <= nc - 1 : (jmin + 63 <= nc - 2 && i < nr - 1));
+    if (interior) {
+      // every lane is an interior point: constant q, scan of the p part only
+      double p = (ad_int * own + beta * frow - wU * upper - wL * lower) * inv_int;
+      p = fma(q0, row_shr<1>(p, lane), p);
+      p = fma(q2, row_shr<2>(p, lane), p);
+      p = fma(q4, row_shr<4>(p, lane), p);
+      p = fma(q8, row_shr<8>(p, lane), p);
+      p = fma(Q15, bcast15(p, lane), p);
+      p = fma(Q31, bcast31(p, lane), p);
+      double c1, c2;
+      carries_of(i, c1, c2);
+      x = fma(qpow, c1, p);
+      v[(long)i * nc + jmin + lane] = x;
+      c1p = c1;
+      c2p = c2;
+    } else {
+      const int j = jmin + lane;
+      const bool valid = j >= 0 && j < nc;
+      const bool last_col = !FIVE && j == nc - 1, last_row = !FIVE && i == nr - 1;
+      // the centre-column / own-row coefficients change on the last column / row (Galerkin levels): redo the sums
+      const double cN = last_col ? a.ccol[0] : cN_int, cS = last_col ? a.ccol[2] : cS_int;
+      const double cW = last_row ? a.crow[0] : cW_int, cE = last_row ? a.crow[2] : cE_int;
+      const double d = last_row ? (last_col ? d_cor : d_row) : (last_col ? d_col : d_int);
+      const double invd = last_row ? (last_col ? inv_cor : inv_row) : (last_col ? inv_col : inv_int);
+      double lo2, up2;
+      if (FIVE) {
+        lo2 = lower;
+        up2 = upper;
+      } else {
+        const double nw = from_left(n, lane) + (lane == 0 ? c2p : 0.0);
+        const double se = from_right(s1, lane) + tl[0];  // (tl was shifted above: tl[0] now is the row below's)
+        lo2 = fma(cNW, nw, fma(cN, n, cNE * ne));
+        up2 = fma(cE, e, fma(cSW, sw, fma(cS, s, cSE * se)));
+      }
+      double p = (alpha * d * own + beta * frow - wU * up2 - wL * lo2) * invd;
+      double qq = -wL * cW * invd;
+      if (!valid) {
+        p = 0.0;
+        qq = 0.0;
+      }
+      // inclusive scan of the maps x -> p + q x over the lanes (`first` applied before `second`:
+      // p = second.p + second.q * first.p, q = second.q * first.q)
 #define MGCMT_LEX_STEP(FETCH, COND)             \
   {                                             \
     const double pp = FETCH(p, lane);           \
@@ -254,35 +314,31 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       qq = qq * pq;                             \
     }                                           \
   }
-    MGCMT_LEX_STEP(row_shr<1>, (lane & 15) >= 1)
-    MGCMT_LEX_STEP(row_shr<2>, (lane & 15) >= 2)
-    MGCMT_LEX_STEP(row_shr<4>, (lane & 15) >= 4)
-    MGCMT_LEX_STEP(row_shr<8>, (lane & 15) >= 8)
-    MGCMT_LEX_STEP(bcast15, (lane & 16) != 0)
-    MGCMT_LEX_STEP(bcast31, lane >= 32)
+      MGCMT_LEX_STEP(row_shr<1>, (lane & 15) >= 1)
+      MGCMT_LEX_STEP(row_shr<2>, (lane & 15) >= 2)
+      MGCMT_LEX_STEP(row_shr<4>, (lane & 15) >= 4)
+      MGCMT_LEX_STEP(row_shr<8>, (lane & 15) >= 8)
+      MGCMT_LEX_STEP(bcast15, (lane & 16) != 0)
+      MGCMT_LEX_STEP(bcast31, lane >= 32)
 #undef MGCMT_LEX_STEP
-    // the value left of lane 0 on this row: the left block's lane 63
-    double c1, c2;
-    carries_of(i, c1, c2);
-    const double x = valid ? fma(qq, c1, p) : 0.0;
-    if (valid) v[(long)i * nc + j] = x;
-    if (publish) {
-      if (lane >= 62) store_shared(my_carry + (long)i * 2 + (63 - lane), x);
-      if (++since_publish == kPublish || i == i1) {
-        since_publish = 0;
-        drain_stores();
-        if (lane == 0) store_word(my_progress, i == i1 ? (unsigned)nr : (unsigned)i + 1u);
-      }
+      double c1, c2;
+      carries_of(i, c1, c2);
+      x = valid ? fma(qq, c1, p) : 0.0;
+      if (valid) v[(long)i * nc + j] = x;
+      c1p = c1;
+      c2p = c2;
+    }
+    if (publish && lane >= 62) {  // {tag, half} granules of lanes 62 / 63: the right block's NW / N / W values
+      const u64 bits = __builtin_bit_cast(u64, x);
+      u64* rec = my_rec + (long)i * 4 + (lane - 62) * 2;
+      store_granule(rec, (1ull << 32) | (bits & 0xffffffffull));
+      store_granule(rec + 1, (1ull << 32) | (bits >> 32));
     }
     prev = x;
-    c1p = c1;
-    c2p = c2;
+    e = s;  // the row below becomes the own row
     if (failed) break;
   }
-  if (failed && lane == 0) {
-    store_word(a.sync + 1, 1u);  // tell the host and release everyone behind this block
-    store_word(my_progress, (unsigned)nr);
-  }
+  if (failed && lane == 0) store_word(a.sync + 1, 1u);  // tell the host and release everyone behind this block
 }
 
 }  // namespace
@@ -293,7 +349,8 @@ bool lex_wave_supported(const KGrid& g, const KOp& op) {
 
 long lex_wave_blocks(const KGrid& g) { return (g.nr + g.nc - 1 + 63) / 64; }
 
-// scratch: carry = k * blocks * nr * 2 doubles, sync = (2 + k * blocks) words; the sync words are cleared here
+// scratch: carry = k * blocks * nr * 4 granules of 8 bytes (cleared here: a record is valid when its tags are set),
+// sync = 2 words (cleared here)
 void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta, double wU,
                      double wL, int k, double* carry, unsigned* sync) {
   LexWaveArgs a{};
@@ -303,6 +360,7 @@ void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.nr = (int)g.nr;
   a.nc = (int)g.nc;
   a.nblocks = (int)lex_wave_blocks(g);
+  a.five = op.five_point ? 1 : 0;
   if (op.five_point) {
     const double c5[3][3] = {{0.0, op.cn, 0.0}, {op.cw, op.c0, op.cw}, {0.0, op.cn, 0.0}};
     for (int i = 0; i < 3; ++i) {
@@ -324,11 +382,13 @@ void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.beta = beta;
   a.wU = wU;
   a.wL = wL;
-  a.carry = carry;
+  a.carry = reinterpret_cast<unsigned long long*>(carry);
   a.sync = sync;
-  a.carry_stride = (long)a.nblocks * g.nr * 2;
-  (void)hipMemsetAsync(sync, 0, sizeof(unsigned) * (2 + (size_t)k * a.nblocks), s);
-  hipLaunchKernelGGL(k_lex_wave, dim3((unsigned)(a.nblocks * k)), dim3(64), 0, s, a);
+  a.carry_stride = (long)a.nblocks * g.nr * 4;
+  (void)hipMemsetAsync(sync, 0, sizeof(unsigned) * 2, s);
+  (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * (size_t)k * a.carry_stride, s);
+  if (a.five) hipLaunchKernelGGL(k_lex_wave<true>, dim3((unsigned)(a.nblocks * k)), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(k_lex_wave<false>, dim3((unsigned)(a.nblocks * k)), dim3(64), 0, s, a);
 }
 
 }  // namespace mgcmt

@@ -281,7 +281,7 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
   const KOp& op = p->levels[l].dA.k;
   if (p->use_lex_wave && p->levels[l].nr == p->levels[l].gr && lex_wave_supported(g, op)) {
     const size_t blocks = (size_t)lex_wave_blocks(g);
-    const size_t need_carry = (size_t)p->nvec * blocks * g.nr * 2, need_sync = 2 + (size_t)p->nvec * blocks;
+    const size_t need_carry = (size_t)p->nvec * blocks * g.nr * 4, need_sync = 2;
     if (need_carry > p->lex_carry_doubles || need_sync > p->lex_sync_words) {
       MG_HIP(hipStreamSynchronize(s));
       if (p->d_rq) (void)hipFree(p->d_rq);

@@ -69,69 +69,117 @@ def shift_invert_eigenpairs(dimension="1d", gridsize=2 ** 7, bad_gridsize=2 ** 4
             "history": history}
 
 
+def nested_iteration_guesses(plan, k, coarse_level, kind, omega, iterations_per_level=1):
+    """Eigenpair guesses by nested iteration (full multigrid for the eigenproblem: the reference's report names it as the
+    next step — PDF p.17 "FMG", p.51 "Volgende stappen" — its code starts from straight interpolation of coarse Lanczos
+    vectors instead, 2DPotMatrixVcycle.py:59-85).  The k lowest eigenpairs of the plan's Galerkin operator on
+    ``coarse_level`` are computed densely on the host (a few hundred unknowns, like the reference's coarse ``eigsh``);
+    on the way up every level takes the interpolated vectors and improves them by ``iterations_per_level`` rounds of
+    the reference's own outer iteration (k-column V-cycle with the coarse eigenvalues as shifts and Gram-Schmidt, then
+    normalisation) on THAT level's operator.  Leaves the guesses in slot F of level 0 (normalised) and returns the
+    shifts.  Parity: unpinned (no reference counterpart); checked against the straight-interpolation guesses by the
+    residuals it produces (tests/test_drivers.py)."""
+    from . import _lib
+    from .operators import StructuredOperator
+    V, F = _lib.SLOT_V, _lib.SLOT_F
+    xf = plan.factors(coarse_level, 0) if plan.dim == 2 else None
+    yf = plan.factors(coarse_level, 1)
+    terms = [((xf[m].copy() if xf is not None else None), yf[m].copy()) for m in range(yf.shape[0])]
+    dense = StructuredOperator("2d" if plan.dim == 2 else "1d", plan.g >> coarse_level, terms).tocsr().toarray()
+    values, vectors = scipy.linalg.eigh(0.5 * (dense + dense.T))
+    shifts = values[:k].copy()
+    for j in range(k):
+        plan.upload(coarse_level, F, j, np.ascontiguousarray(vectors[:, j]))
+    for l in range(coarse_level - 1, -1, -1):
+        for j in range(k):
+            plan.prolong(l, (F, j), (F, j), accumulate=False)
+        plan.normalize(l, F, k)
+        if l > 0:
+            for _ in range(int(iterations_per_level)):
+                plan.set_shifts(shifts)
+                plan.vcycle(4, 4, kind, omega=omega, k=k, nu_coarse=4, gram_schmidt=True, level=l, zero_start=True)
+                plan.normalize(l, V, k)
+                for j in range(k):
+                    plan.copy(l, V, j, F, j)
+    return shifts
+
+
 def shift_invert_eigenpairs_resident(dimension="2d", gridsize=2 ** 10, bad_gridsize=2 ** 4, num_eigenvalues=10, max_iters=5,
-                                     lowest_level=None, tolerance=1e-4, guesses=None, smoother=None, stats=None):
-    """The same outer loop as ``shift_invert_eigenpairs`` (1DPotMatrixVcycle.py:42-80 / 2DPotMatrixVcycle.py:54-109)
-    with everything between the coarse-grid Lanczos guesses and the final download resident on the GPU: the guesses
-    are interpolated level by level inside the plan, every iteration is one k-column V-cycle with Gram-Schmidt
-    (the reference's vcycle_matrix), a column normalisation, k device copies and k Rayleigh quotients (one operator
-    application and one two-vector Gram pass each).  For grids whose k columns are too large to shuttle over PCIe
-    every iteration (or to assemble as a sparse matrix at all).  Returns the same dict; ``stats`` receives the seconds
-    spent in the iteration loop."""
+                                     lowest_level=None, tolerance=1e-4, guesses=None, smoother=None, stats=None,
+                                     gram_schmidt="inside", residuals=None, guess_method="interpolate"):
+    """The outer loops of 1DPotMatrixVcycle.py:42-80 / 2DPotMatrixVcycle.py:54-109 / 1DPotMGS.py:50-127 with everything
+    between the coarse-grid guesses and the final download resident on the GPU: the guesses are interpolated level by
+    level inside the plan; every iteration is one k-column V-cycle (one shift per column), a column normalisation, k
+    device copies, and ONE batched pass that yields all k Rayleigh quotients and residual norms ||(H - mu_j) v_j||
+    (2DPotMatrixVcycle.py:100-105) with a single synchronisation (mgcmt_rayleigh_residual).
+
+    gram_schmidt: where the columns are orthogonalised — the three variants 1DPotMGS.py compares:
+      "inside"  at every level on the way up of the cycle (vcycle_matrix, MGCMTSolver.py:434; 1DPotMGS.py:104-124)
+      "after"   once per outer iteration, after normalisation and after the Rayleigh quotients are taken (:77-98)
+      "none"    never: k independent single-vector cycles (:50-72)
+    guess_method: "interpolate" (the reference: coarse eigenvectors interpolated straight to the fine grid) or "fmg"
+    (``nested_iteration_guesses``; ``guesses`` is then ignored and bad_gridsize names the coarsest eigen-grid).
+    Returns dict(eigenvalues, eigenvectors, guess_eigenvalues, history[, residual_history]); ``residuals`` (a list)
+    also receives the residual norms after every iteration; ``stats`` the seconds spent in the iteration loop."""
     import time
     from . import _lib
     from .operators import laplacian_operator
     from .plan import Plan
+    if gram_schmidt not in ("inside", "after", "none"):
+        raise ValueError("gram_schmidt must be 'inside', 'after' or 'none'")
     stencil_maker, solver = MGCMTStencilMaker(), MGCMTSolver()
     g, k = int(gridsize), int(num_eigenvalues)
     if lowest_level is None:
         lowest_level = 2 ** 4 if dimension == "1d" else 2 ** 3
     lowest_level = min(int(lowest_level), int(bad_gridsize))
-    if guesses is None:
-        bad_hamiltonian = (-1. / np.pi ** 2) * stencil_maker.laplacian(bad_gridsize, dimension=dimension)
-        bad_eigenvalues, bad_eigenvectors = sparsela.eigsh(bad_hamiltonian, k=k, which="SM", tol=tolerance)
-    else:
-        bad_eigenvalues, bad_eigenvectors = guesses
-    bad_eigenvalues, bad_eigenvectors = np.asarray(bad_eigenvalues, dtype=float), np.array(bad_eigenvectors, dtype=float)
     kind, omega = solver._resolve_smoother(smoother)
     if kind is None:
         raise NotImplementedError("the device-resident loop takes MGCMTSolver's own smoothers; use shift_invert_eigenpairs for a callable")
-    V, F, W = _lib.SLOT_V, _lib.SLOT_F, _lib.SLOT_W
+    V, F = _lib.SLOT_V, _lib.SLOT_F
     plan = Plan(laplacian_operator(g, dimension) * (-1 / np.pi ** 2), lowest_level, nvec=k)
     try:
         lb = (g // int(bad_gridsize)).bit_length() - 1          # level of the guess grid
-        for j in range(k):
-            plan.upload(lb, F, j, bad_eigenvectors[:, j])
-            for l in range(lb - 1, -1, -1):
-                plan.prolong(l, (F, j), (F, j), accumulate=False)
-        plan.normalize(0, F, k)
-        plan.set_shifts(np.zeros(k))
-
-        def rayleigh_quotients(slot):
-            out = np.zeros(k)
+        if guess_method == "fmg":
+            bad_eigenvalues = nested_iteration_guesses(plan, k, lb, kind, omega)
+        elif guess_method == "interpolate":
+            if guesses is None:
+                bad_hamiltonian = (-1. / np.pi ** 2) * stencil_maker.laplacian(bad_gridsize, dimension=dimension)
+                bad_eigenvalues, bad_eigenvectors = sparsela.eigsh(bad_hamiltonian, k=k, which="SM", tol=tolerance)
+            else:
+                bad_eigenvalues, bad_eigenvectors = guesses
+            bad_eigenvalues, bad_eigenvectors = np.asarray(bad_eigenvalues, dtype=float), np.array(bad_eigenvectors, dtype=float)
             for j in range(k):
-                plan.apply(0, (slot, j), (W, j))
-                out[j] = plan.gram(0, [(slot, j), (W, j)])[0, 1]
-            return out
+                plan.upload(lb, F, j, bad_eigenvectors[:, j])
+                for l in range(lb - 1, -1, -1):
+                    plan.prolong(l, (F, j), (F, j), accumulate=False)
+            plan.normalize(0, F, k)
+        else:
+            raise ValueError("guess_method must be 'interpolate' or 'fmg'")
+        plan.set_shifts(bad_eigenvalues)
 
         history = np.zeros((max_iters + 1, k))
-        history[0] = rayleigh_quotients(F)
+        residual_history = np.zeros((max_iters + 1, k))
+        history[0], residual_history[0] = plan.rayleigh_residual(0, F, k)
         plan.sync()
         start = time.perf_counter()
         for it in range(1, max_iters + 1):
-            plan.set_shifts(bad_eigenvalues)
-            plan.vcycle(4, 4, kind, omega=omega, k=k, nu_coarse=4, gram_schmidt=True, zero_start=True)
+            plan.vcycle(4, 4, kind, omega=omega, k=k, nu_coarse=4, gram_schmidt=(gram_schmidt == "inside"), zero_start=True)
             plan.normalize(0, V, k)
             for j in range(k):
                 plan.copy(0, V, j, F, j)
-            history[it] = rayleigh_quotients(F)
+            history[it], residual_history[it] = plan.rayleigh_residual(0, F, k)
+            if residuals is not None:
+                residuals.append(residual_history[it].copy())
+            if gram_schmidt == "after":
+                plan.gramschmidt(0, F, k, modified=1)        # processor.gramschmidt(eigenvectors), 1DPotMGS.py:98
         plan.sync()
         if stats is not None:
             stats["loop_seconds"] = time.perf_counter() - start
         vectors = np.stack([plan.download(0, F, j) for j in range(k)], axis=1)
     finally:
         plan.close()
-    return {"eigenvalues": history[-1].copy(), "eigenvectors": vectors, "guess_eigenvalues": bad_eigenvalues, "history": history}
+    return {"eigenvalues": history[-1].copy(), "eigenvectors": vectors, "guess_eigenvalues": np.asarray(bad_eigenvalues),
+            "history": history, "residual_history": residual_history}
 
 
 def rayleigh_quotient_multigrid(gridsize=2 ** 6, first_cycles=2, second_cycles=10, seed=0):

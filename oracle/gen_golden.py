@@ -276,6 +276,40 @@ def main():
             hist[it, j] = V[:, j] @ (H @ V[:, j])
     save("driver_2dpot_matrix_vcycle", bad_vals=bad_vals, bad_vecs=bad_vecs, V0=V0, V_final=V,
          rq_history=hist, residual_history=res)
+    # 1DPotMGS.py:14-127 at the script's own sizes (n = 256, guesses from 8, 6 pairs, 10 iterations, lowest level 8):
+    # the three Gram-Schmidt placements it compares — none (:50-72), after every outer iteration (:77-98), inside the
+    # cycle (vcycle_matrix, :104-124) — from the same ARPACK guesses
+    g, bad, k, iters, low = 2 ** 8, 2 ** 3, 6, 10, 2 ** 3
+    H = (-1 / np.pi ** 2) * sm.laplacian(g)
+    Hb = (-1 / np.pi ** 2) * sm.laplacian(bad)
+    bad_vals, bad_vecs = sla.eigsh(Hb, k=k, which="SM", tol=1e-4)
+    bad_vecs = np.array(bad_vecs)
+    P = sm.interpolation(bad, g)
+    mgs = {"bad_vals": bad_vals, "bad_vecs": bad_vecs}
+    for placement in ("none", "after", "inside"):
+        V = np.zeros((g, k))
+        hist = np.zeros((iters + 1, k))
+        for j in range(k):
+            V[:, j] = P * bad_vecs[:, j]
+            V[:, j] /= np.linalg.norm(V[:, j])
+            hist[0, j] = np.dot(V[:, j].conj().T, H.dot(V[:, j]))
+        for it in range(1, iters + 1):
+            if placement == "inside":
+                w = solver.vcycle_matrix(np.zeros((g, k)), V.copy(), H, sm, shifts=bad_vals, lowest_level=low)
+                for j in range(k):
+                    V[:, j] = w[:, j] / np.linalg.norm(w[:, j])
+                    hist[it, j] = np.dot(V[:, j].conj().T, H.dot(V[:, j]))
+            else:
+                for j in range(k):
+                    w = solver.vcycle(np.zeros((g, 1)), V[:, j].copy(), H, sm, shift=bad_vals[j], lowest_level=low)
+                    V[:, j] = w / np.linalg.norm(w)
+                    hist[it, j] = np.dot(V[:, j].conj().T, H.dot(V[:, j]))
+                if placement == "after":
+                    V = proc.gramschmidt(V)
+        mgs["rq_history_" + placement] = hist
+        mgs["V_final_" + placement] = V.copy()
+    save("driver_1dpot_mgs", **mgs)
+
     # ---- BASELINE config 5 at a size the reference can run: square-well Hamiltonian on a 2-D grid -------------------
     # H = -laplacian/pi^2 + diag(V), V = depth outside the square [lo,hi)^2 (the potential of PotWellSolver.py:150-153
     # carried to two dimensions), through the reference's own vcycle (2-D transfers) and rqmin (RQMin.py:18-27)

@@ -88,3 +88,42 @@ def test_resident_driver_equals_host_driver(backend, dimension, g, bad, fixture,
     for j in range(k):
         assert rel_err(res["eigenvectors"][:, j], host["eigenvectors"][:, j]) < 1e-9
     assert stats["loop_seconds"] > 0
+
+
+@pytest.mark.parametrize("placement", ["none", "after", "inside"])
+def test_gram_schmidt_placements_of_1dpot_mgs(backend, placement):
+    """1DPotMGS.py:50-127 at the script's own sizes: the Rayleigh-quotient history of each Gram-Schmidt placement,
+    computed by the reference itself (tests/golden/driver_1dpot_mgs.npz), from the device-resident loop."""
+    gold = load_golden("driver_1dpot_mgs")
+    out = drivers.shift_invert_eigenpairs_resident("1d", 256, 8, 6, 10, lowest_level=8, guesses=(gold["bad_vals"], gold["bad_vecs"]),
+                                                   gram_schmidt=placement)
+    want = gold["rq_history_" + placement]
+    assert np.allclose(out["history"], want, rtol=1e-10, atol=0), np.abs(out["history"] / want - 1).max()
+    V, Vref = out["eigenvectors"], gold["V_final_" + placement]
+    for j in range(6):
+        sign = np.sign(np.dot(V[:, j], Vref[:, j]))
+        assert rel_err(sign * V[:, j], Vref[:, j]) < 1e-8, (placement, j)
+
+
+def test_residual_history_of_2dpot_matrix_vcycle(backend):
+    """2DPotMatrixVcycle.py:100-101: ||(H - mu_i I) v_i|| per column and iteration, all columns from one batched pass."""
+    gold = load_golden("driver_2dpot_matrix_vcycle")
+    k = gold["bad_vecs"].shape[1]
+    seen = []
+    out = drivers.shift_invert_eigenpairs_resident("2d", 32, 8, k, 3, lowest_level=4, guesses=(gold["bad_vals"], gold["bad_vecs"]),
+                                                   residuals=seen)
+    assert np.allclose(out["residual_history"][1:], gold["residual_history"], rtol=1e-9, atol=1e-13)
+    assert np.allclose(out["history"][1:], gold["rq_history"], rtol=1e-10, atol=0)
+    assert len(seen) == 3 and np.array_equal(seen[-1], out["residual_history"][-1])
+
+
+def test_nested_iteration_guesses(backend):
+    """guess_method="fmg" (an addition; parity unpinned — the reference has no FMG code): the guesses it hands to the
+    outer loop are better than straight interpolation of the coarse eigenvectors (smaller residuals at iteration 0) and
+    the loop converges to the same eigenvalues."""
+    k = 4
+    plain = drivers.shift_invert_eigenpairs_resident("2d", 128, 16, k, 3, lowest_level=8, tolerance=1e-12)
+    fmg = drivers.shift_invert_eigenpairs_resident("2d", 128, 16, k, 3, lowest_level=8, guess_method="fmg")
+    exact = drivers.exact_box_eigenvalues(128, "2d", k)
+    assert np.all(fmg["residual_history"][0] < plain["residual_history"][0])
+    assert abs(np.sort(fmg["eigenvalues"])[0] - exact[0]) < 1e-5 and np.allclose(np.sort(fmg["eigenvalues"]), exact, atol=2e-3)
