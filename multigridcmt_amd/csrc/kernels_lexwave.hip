@@ -149,37 +149,49 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // the grid read as zero.
   auto load_window = [&](int r, double& w, double& t, double& fr) {
     const int rr = r < nr ? r : nr;
-    const int jw = J * 64 + lane - r;
+    const int jw0 = J * 64 - r;  // lane 0's column on row r
+    const double* row = v + (long)rr * nc;
+    const double* frow_ = f + (long)rr * nc;
+    if (jw0 >= 0 && jw0 + 65 <= nc - 1) {  // the window and the two columns to its right lie inside the grid
+      w = row[jw0 + lane];
+      t = 0.0;
+      if (lane >= 62) t = row[jw0 + lane + 2];
+      fr = frow_[jw0 + lane];
+      return;
+    }
+    const int jw = jw0 + lane;
     const int jt = jw + 2;  // lanes 62, 63: columns J*64 + 64 - r and + 65 - r
     const int jwc = jw < 0 ? 0 : (jw > nc - 1 ? nc - 1 : jw);
     const int jtc = jt < 0 ? 0 : (jt > nc - 1 ? nc - 1 : jt);
-    const double* row = v + (long)rr * nc;
     const double wv = row[jwc];
     double tv = 0.0;
     if (lane >= 62) tv = row[jtc];
-    fr = f[(long)rr * nc + jwc];
+    fr = frow_[jwc];
     w = (jw >= 0 && jw < nc) ? wv : 0.0;
     t = (lane >= 62 && jt >= 0 && jt < nc) ? tv : 0.0;
   };
 
-  // edge records of the left block: lane l holds granule (l & 3) of row cbase + (l >> 2); rows [cbase, cbase + cvalid)
-  // of the batch were complete when it was loaded
-  int cbase = -(1 << 30), cvalid = 0;
-  bool cchecked = true, failed = false;
-  u64 R = 0;
-  auto issue_batch = [&](int row) {  // no wait: the load is consumed by check_batch
-    cbase = row;
-    cchecked = false;
-    R = load_granule(left_rec + (long)row * 4 + lane);
-  };
-  auto check_batch = [&]() {
+  // edge records of the left block: lane l of a batch holds granule (l & 3) of row base + (l >> 2).  Rows
+  // [cbase, cbase + cvalid) of the CURRENT batch were complete when it was loaded; the NEXT batch (the rows behind them)
+  // is requested two rows before the current one runs out, so its round trip to L2 hides behind those rows.
+  int cbase = 0, cvalid = 0, nbase = 0;
+  bool next_pending = false, failed = false;
+  u64 Rc = 0, Rn = 0;
+  auto valid_rows = [&](u64 R, int base) {
     const u64 m = vote((unsigned)(R >> 32) == 1u);
     const u64 full = m & (m >> 1) & (m >> 2) & (m >> 3) & 0x1111111111111111ull;
     const u64 gap = ~full & 0x1111111111111111ull;
     int n = gap ? (int)(__builtin_ctzll(gap) >> 2) : kBatch;
-    if (cbase + n > left_last + 1) n = left_last + 1 - cbase;  // (records beyond the left block's last row do not exist)
-    cvalid = n < 0 ? 0 : n;
-    cchecked = true;
+    if (base + n > left_last + 1) n = left_last + 1 - base;  // (records beyond the left block's last row do not exist)
+    return n < 0 ? 0 : n;
+  };
+  auto request_next = [&](int i) {  // called at the start of row i
+    if (J == 0 || next_pending || i > left_last) return;
+    const int first_missing = cbase + cvalid;
+    if (i + 2 < first_missing || first_missing > left_last) return;
+    nbase = first_missing > i ? first_missing : i;
+    Rn = load_granule(left_rec + (long)nbase * 4 + lane);
+    next_pending = true;
   };
   auto carries_of = [&](int row, double& c1, double& c2) {
     if (J == 0 || row < 0 || row > left_last) {  // no left block there: Dirichlet zero
@@ -187,32 +199,40 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       c2 = 0.0;
       return;
     }
-    if (!cchecked) check_batch();
     if (!(row >= cbase && row < cbase + cvalid)) {
-      u64 t0 = 0;
-      bool timing = false;
-      while (true) {
-        issue_batch(row);
-        check_batch();
-        if (cvalid > 0) break;
-        if (!timing) {
-          t0 = now_ticks();
-          timing = true;
-        }
-        nap();
-        if (now_ticks() - t0 > kTimeoutTicks || load_word(a.sync + 1) != 0u) {
-          failed = true;
-          break;
-        }
+      if (next_pending) {  // the batch requested earlier becomes the current one
+        Rc = Rn;
+        cbase = nbase;
+        cvalid = valid_rows(Rc, cbase);
+        next_pending = false;
       }
-      if (failed) {
-        c1 = 0.0;
-        c2 = 0.0;
-        return;
+      if (!(row >= cbase && row < cbase + cvalid)) {  // not there yet: ask until it is
+        u64 t0 = 0;
+        bool timing = false;
+        while (true) {
+          cbase = row;
+          Rc = load_granule(left_rec + (long)row * 4 + lane);
+          cvalid = valid_rows(Rc, cbase);
+          if (cvalid > 0) break;
+          if (!timing) {
+            t0 = now_ticks();
+            timing = true;
+          }
+          nap();
+          if (now_ticks() - t0 > kTimeoutTicks || load_word(a.sync + 1) != 0u) {
+            failed = true;
+            break;
+          }
+        }
+        if (failed) {
+          c1 = 0.0;
+          c2 = 0.0;
+          return;
+        }
       }
     }
     const int k = (row - cbase) * 4;
-    const u64 g0 = lane_bits(R, k), g1 = lane_bits(R, k + 1), g2 = lane_bits(R, k + 2), g3 = lane_bits(R, k + 3);
+    const u64 g0 = lane_bits(Rc, k), g1 = lane_bits(Rc, k + 1), g2 = lane_bits(Rc, k + 2), g3 = lane_bits(Rc, k + 3);
     c2 = __builtin_bit_cast(double, (g0 & 0xffffffffull) | (g1 << 32));  // the left block's lane 62
     c1 = __builtin_bit_cast(double, (g2 & 0xffffffffull) | (g3 << 32));  // ... lane 63
   };
@@ -257,9 +277,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       fr[dd] = fr[dd + 1];
     }
     load_window(i + kDepth + 1, wn[kDepth], tl[kDepth], fr[kDepth]);
-    // the left block's edge values of this row: ask for them now if the batch at hand does not hold them
-    const bool left_here = J > 0 && i <= left_last;
-    if (left_here && cchecked && !(i >= cbase && i < cbase + cvalid)) issue_batch(i);
+    request_next(i);  // the left block's edge values of the rows ahead
 
     double x;
     const bool interior = jmin >= 0 && (FIVE ? jmin + 63 <= nc - 1 : (jmin + 63 <= nc - 2 && i < nr - 1));

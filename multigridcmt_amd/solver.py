@@ -383,7 +383,7 @@ class MGCMTSolver:
     _X, _P, _G, _GOLD, _AX, _AP, _MX, _MP, _TMP, _TMP2 = range(10)
     _RQ_REGS = 10
 
-    def _rqmin_device(self, plan, level, nu):
+    def _rqmin_device(self, plan, level, nu, robust=False):
         """rqmin (MGCMTSolver.py:17-57) on the registers of `level`; x is register _X.  The vector work (6 operator
         applications and a handful of fused passes per step) runs on the GPU: every group of inner products the
         reference takes one by one (:19-21, :34-35, :44-47) is ONE Gram-matrix pass with one host round trip
@@ -419,8 +419,22 @@ class MGCMTSolver:
             gm = plan.gram(level, [X, P, AX, AP, MX, MP])
             R = np.array([[gm[0, 2], gm[0, 3]], [gm[1, 2], gm[1, 3]]])
             RM = np.array([[gm[0, 4], gm[0, 5]], [gm[1, 4], gm[1, 5]]])
-            w, vecs = scipy.linalg.eig(R, b=RM)
-            y = vecs[:, np.argmin(w)]
+            if robust:
+                # repaired variant ((f)4): a degenerate 2x2 pencil — the search direction vanished or is parallel to x, as
+                # happens with two orthogonal columns on a 2-point grid (the reference then dies inside eig with
+                # "array must not contain infs or NaNs") — ends the minimisation on this level instead
+                RM_s = 0.5 * (RM + RM.T)
+                scale = max(abs(RM_s[0, 0]), 1e-300)
+                if not np.all(np.isfinite(R)) or not np.all(np.isfinite(RM_s)) or RM_s[1, 1] <= 1e-28 * scale or \
+                        np.linalg.det(RM_s) <= 1e-14 * RM_s[0, 0] * RM_s[1, 1]:
+                    break
+                w, vecs = scipy.linalg.eigh(0.5 * (R + R.T), b=RM_s)
+                y = vecs[:, 0]
+                if abs(y[0]) <= 1e-14 * abs(y[1]):
+                    break
+            else:
+                w, vecs = scipy.linalg.eig(R, b=RM)
+                y = vecs[:, np.argmin(w)]
             delta = float(np.real(y[1] / y[0]))
             plan.axpy(level, delta, P, X)
             rho = rayleigh()
@@ -448,13 +462,13 @@ class MGCMTSolver:
         rho = self._rqmin_device(plan, 0, int(nu))
         return plan.download(0, SLOT_V, self._X), rho
 
-    def _rqmg_levels(self, plan, level, nu1, nu2):
-        rho = self._rqmin_device(plan, level, nu1)
+    def _rqmg_levels(self, plan, level, nu1, nu2, robust=False):
+        rho = self._rqmin_device(plan, level, nu1, robust)
         if level + 1 < plan.num_levels:
             plan.restrict(level, (SLOT_V, self._X), (SLOT_V, self._X))             # k_coarse = R k   (:113)
-            _, rho = self._rqmg_levels(plan, level + 1, nu1, nu2)
+            _, rho = self._rqmg_levels(plan, level + 1, nu1, nu2, robust)
             plan.prolong(level, (SLOT_V, self._X), (SLOT_V, self._X), accumulate=True)  # k += P c   (:116-118)
-            rho = self._rqmin_device(plan, level, nu2)
+            rho = self._rqmin_device(plan, level, nu2, robust)
         return None, rho
 
     def vcycle_rqmg(self, x, A, M, nu1=4, nu2=4, nmin=2):
@@ -470,9 +484,12 @@ class MGCMTSolver:
         _, rho = self._rqmg_levels(plan, 0, int(nu1), int(nu2))
         return plan.download(0, SLOT_V, self._X), rho
 
-    def vcycle_rqmg2(self, x_matrix, A, M, nu1=4, nu2=4, nmin=2, level=0):
+    def vcycle_rqmg2(self, x_matrix, A, M, nu1=4, nu2=4, nmin=2, level=0, *, repaired=False):
         """MGCMTSolver.py:59-94 — multi-vector variant: rqmin per column, four Gram-Schmidt passes on
-        the finest level (:69-71), recursion on the restricted columns, correction and rqmin per column."""
+        the finest level (:69-71), recursion on the restricted columns, correction and rqmin per column.
+        ``repaired`` (addition): with the default nmin=2 the reference dies inside ``eig`` (two
+        orthogonal columns degenerate on a 2-point grid); repaired=True ends a level's minimisation when its 2x2
+        pencil degenerates and solves it with ``eigh`` on the symmetrised matrices, so the default arguments run."""
         k0 = np.array(x_matrix, dtype=np.float64)
         n, nv = k0.shape
         if nv > _lib.MAX_VEC:
@@ -482,16 +499,16 @@ class MGCMTSolver:
         plan.set_shifts(np.zeros(plan.nvec))
         for i in range(nv):
             plan.upload(0, SLOT_W, i, k0[:, i])
-        self._rqmg2_levels(plan, 0, nv, int(nu1), int(nu2))
+        self._rqmg2_levels(plan, 0, nv, int(nu1), int(nu2), bool(repaired))
         out = np.zeros((n, nv))
         for i in range(nv):
             out[:, i] = plan.download(0, SLOT_W, i)
         return out
 
-    def _rqmg2_levels(self, plan, level, nv, nu1, nu2):
+    def _rqmg2_levels(self, plan, level, nv, nu1, nu2, robust=False):
         for i in range(nv):
             plan.copy(level, SLOT_W, i, SLOT_V, self._X)
-            self._rqmin_device(plan, level, nu1)
+            self._rqmin_device(plan, level, nu1, robust)
             plan.copy(level, SLOT_V, self._X, SLOT_W, i)
         if level == 0:
             for _ in range(4):
@@ -499,14 +516,31 @@ class MGCMTSolver:
         if level + 1 < plan.num_levels:
             for i in range(nv):
                 plan.restrict(level, (SLOT_W, i), (SLOT_W, i))
-            self._rqmg2_levels(plan, level + 1, nv, nu1, nu2)
+            self._rqmg2_levels(plan, level + 1, nv, nu1, nu2, robust)
             for i in range(nv):
                 plan.prolong(level, (SLOT_W, i), (SLOT_W, i), accumulate=True)
                 plan.copy(level, SLOT_W, i, SLOT_V, self._X)
-                self._rqmin_device(plan, level, nu2)
+                self._rqmin_device(plan, level, nu2, robust)
                 plan.copy(level, SLOT_V, self._X, SLOT_W, i)
 
-    def twogridrqmin(self, A, v0, M, nu1=4, nu2=4):
-        """MGCMTSolver.py:127-178 is dead code in the reference (it calls ``eigh`` which is never
-        imported, :167 vs :4, and raises NameError on first use)."""
-        raise NameError("name 'eigh' is not defined")
+    def twogridrqmin(self, A, v0, M, nu1=4, nu2=4, *, repaired=False):
+        """MGCMTSolver.py:127-178 is dead code in the reference: it calls ``eigh`` which is never imported (:167 vs :4)
+        and raises NameError on first use — reproduced by default.
+
+        ``repaired=True`` (addition) runs what the function is the two-grid form of: the reference's own
+        Rayleigh-quotient multigrid (vcycle_rqmg, :99-122) cut off after one coarsening — rqmin on the fine grid (:133),
+        the iterate restricted (:141), the coarse pair (R A P, R M P) minimised with nu1 rqmin steps (the loop of
+        :151-174, whose x_coarse the dead code never updates), the interpolated coarse iterate added (:170) and nu2
+        fine-grid rqmin steps (:176).  Equal to ``vcycle_rqmg(v0, A, M, nu1, nu2, nmin=n/2)`` of the reference
+        (fixture tests/golden/rqmin.npz: twogrid_*)."""
+        if not repaired:
+            raise NameError("name 'eigh' is not defined")
+        x0 = np.asarray(v0, dtype=np.float64).reshape(-1)
+        g = recognise(A).g
+        if g < 4:
+            raise ValueError("twogridrqmin needs at least 4 points per direction")
+        plan = self._rq_plan(A, M, g // 2)
+        plan.set_shifts(np.zeros(self._RQ_REGS))
+        plan.upload(0, SLOT_V, self._X, x0)
+        _, rho = self._rqmg_levels(plan, 0, int(nu1), int(nu2), robust=True)
+        return plan.download(0, SLOT_V, self._X), rho

@@ -223,6 +223,9 @@ def main():
         rhos.append(np.real(rho))
     rq["rqmg_x"], rq["rqmg_rhos"] = np.real(x), np.array(rhos)
     rq["rqmg_rho_survey"] = np.array(0.9706044628745033)
+    # the two-grid form of the same algorithm (what the dead twogridrqmin, :127-178, is the skeleton of): one coarsening
+    x, rho = solver.vcycle_rqmg(_c(x0), A64, M64, nu1=4, nu2=4, nmin=32)
+    rq["twogrid_x"], rq["twogrid_rho"] = np.real(x), np.real(rho)
     A32 = (-1 / np.pi ** 2) * sm.laplacian(32)
     X0 = np.random.RandomState(0).rand(32, 2)
     rq["X0"] = X0

@@ -242,6 +242,28 @@ def test_rqmin_family(trio):
         solver.twogridrqmin(A, gold["x0"], M)                          # dead code in the reference (:167)
 
 
+def test_repaired_rayleigh_quotient_variants(trio):
+    """SURVEY §8 (f)4.  twogridrqmin(repaired=True) is the reference's own Rayleigh-quotient multigrid cut off after one
+    coarsening: pinned by the reference's vcycle_rqmg(..., nmin=n/2) (fixture rqmin.npz: twogrid_*).  vcycle_rqmg2 with
+    the reference's DEFAULT nmin=2 dies inside eig in the reference (degenerate 2x2 pencil); repaired=True runs it:
+    parity unpinned (nothing to compare with) — checked by what it must do: finite columns, orthonormal after the
+    Gram-Schmidt passes of level 0, Rayleigh quotients no worse than the nmin=4 run the reference can do."""
+    solver, sm, _ = trio
+    gold = load_golden("rqmin")
+    A, M = H(sm, 64), sp.eye(64)
+    x, rho = solver.twogridrqmin(A, gold["x0"], M, repaired=True)
+    assert abs(rho - float(gold["twogrid_rho"])) < NORTH_STAR * abs(float(gold["twogrid_rho"]))
+    assert rel_err(np.sign(np.dot(x, gold["twogrid_x"])) * x, gold["twogrid_x"]) < 1e-9
+    A32 = H(sm, 32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X2 = solver.vcycle_rqmg2(gold["X0"], A32, sp.eye(32), repaired=True)               # nmin=2, the default
+        X4 = solver.vcycle_rqmg2(gold["X0"], A32, sp.eye(32), nmin=4)
+    assert np.all(np.isfinite(X2))
+    rq = lambda X: np.array([X[:, i] @ (A32 @ X[:, i]) / (X[:, i] @ X[:, i]) for i in range(2)])
+    assert np.all(rq(X2) < rq(X4) * 1.05) and rq(X2)[0] < 1.0
+
+
 @pytest.mark.parametrize("name,dim,g,low", [("driver_1dpot_matrix_vcycle", "1d", 128, 16),
                                             ("driver_2dpot_matrix_vcycle", "2d", 32, 4)])
 def test_driver_reenactment(trio, name, dim, g, low):
