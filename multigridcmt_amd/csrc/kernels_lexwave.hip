@@ -15,10 +15,10 @@
 //
 // Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, "the data is the flag"): the two edge values of a row
 // travel as four 8-byte granules {tag, half a double}, each written by ONE agent-scope atomic store (write-through,
-// sc1) into a buffer cleared before the launch; the consumer reads 16 rows of granules with one agent-scope atomic
-// load per lane (sc1: it bypasses its CU's L1) and takes the rows whose four tags are set — no flag, no fence, no
-// drain of the producer's memory pipeline; the load is issued a row ahead of its use, so a consumer that runs a few
-// rows behind its producer never waits.  Block numbers are handed out by a
+// sc1) into a buffer cleared before the launch; the consumer reads them with agent-scope atomic loads (sc1: they bypass
+// its CU's L1) and takes a row when its four tags are set — no flag, no fence, no drain of the producer's memory
+// pipeline; the load is issued two rows ahead of its use, so a consumer that runs a few rows behind its producer never
+// waits.  Block numbers are handed out by a
 // ticket counter, so a block only ever waits for one that has already started; every spin is bounded by a timeout
 // that raises an error word instead of hanging the GPU.
 //
@@ -31,7 +31,6 @@ namespace mgcmt {
 namespace {
 
 constexpr int kDepth = 3;   // rows of old values in flight ahead of the row being processed
-constexpr int kBatch = 16;  // rows of the left block's edge records fetched by one load instruction (4 granules each)
 
 struct LexWaveArgs {
   double* v;
@@ -146,105 +145,66 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
 
   // old values: window of row r = v[r][J*64 + lane - r] (this block's columns on that row); T = the two columns to its
   // right, held by lanes 62 (first) and 63 (second), zero elsewhere.  Rows nr.. are the zero halo rows; columns outside
-  // the grid read as zero.
+  // the grid read as zero.  The loads are UNCONDITIONAL (clamped addresses, values masked afterwards) and there is no
+  // branch around any memory instruction of the row loop, so the compiler counts the loads in flight exactly
+  // (s_waitcnt vmcnt(N), N > 0) instead of draining the memory pipeline every row.
   auto load_window = [&](int r, double& w, double& t, double& fr) {
     const int rr = r < nr ? r : nr;
-    const int jw0 = J * 64 - r;  // lane 0's column on row r
-    const double* row = v + (long)rr * nc;
-    const double* frow_ = f + (long)rr * nc;
-    if (jw0 >= 0 && jw0 + 65 <= nc - 1) {  // the window and the two columns to its right lie inside the grid
-      w = row[jw0 + lane];
-      t = 0.0;
-      if (lane >= 62) t = row[jw0 + lane + 2];
-      fr = frow_[jw0 + lane];
-      return;
-    }
-    const int jw = jw0 + lane;
+    const int jw = J * 64 - r + lane;
     const int jt = jw + 2;  // lanes 62, 63: columns J*64 + 64 - r and + 65 - r
     const int jwc = jw < 0 ? 0 : (jw > nc - 1 ? nc - 1 : jw);
     const int jtc = jt < 0 ? 0 : (jt > nc - 1 ? nc - 1 : jt);
+    const double* row = v + (long)rr * nc;
     const double wv = row[jwc];
-    double tv = 0.0;
-    if (lane >= 62) tv = row[jtc];
-    fr = frow_[jwc];
+    const double tv = row[jtc];
+    fr = f[(long)rr * nc + jwc];
     w = (jw >= 0 && jw < nc) ? wv : 0.0;
     t = (lane >= 62 && jt >= 0 && jt < nc) ? tv : 0.0;
   };
 
-  // edge records of the left block: lane l of a batch holds granule (l & 3) of row base + (l >> 2).  Rows
-  // [cbase, cbase + cvalid) of the CURRENT batch were complete when it was loaded; the NEXT batch (the rows behind them)
-  // is requested two rows before the current one runs out, so its round trip to L2 hides behind those rows.
-  int cbase = 0, cvalid = 0, nbase = 0;
-  bool next_pending = false, failed = false;
-  u64 Rc = 0, Rn = 0;
-  auto valid_rows = [&](u64 R, int base) {
-    const u64 m = vote((unsigned)(R >> 32) == 1u);
-    const u64 full = m & (m >> 1) & (m >> 2) & (m >> 3) & 0x1111111111111111ull;
-    const u64 gap = ~full & 0x1111111111111111ull;
-    int n = gap ? (int)(__builtin_ctzll(gap) >> 2) : kBatch;
-    if (base + n > left_last + 1) n = left_last + 1 - base;  // (records beyond the left block's last row do not exist)
-    return n < 0 ? 0 : n;
+  // edge records of the left block: the four granules of a row are read by lanes 0..3 (every lane loads, the address
+  // is clamped), two rows before they are needed, so their round trip to L2 hides behind those rows
+  const u64* rec_src = J > 0 ? left_rec : my_rec;  // (block 0 has no left neighbour: any valid address, result unused)
+  auto load_record = [&](int row) {
+    const int rc = row < 0 ? 0 : (row > nr - 1 ? nr - 1 : row);
+    return load_granule(rec_src + (long)rc * 4 + (lane & 3));
   };
-  auto request_next = [&](int i) {  // called at the start of row i
-    if (J == 0 || next_pending || i > left_last) return;
-    const int first_missing = cbase + cvalid;
-    if (i + 2 < first_missing || first_missing > left_last) return;
-    nbase = first_missing > i ? first_missing : i;
-    Rn = load_granule(left_rec + (long)nbase * 4 + lane);
-    next_pending = true;
-  };
-  auto carries_of = [&](int row, double& c1, double& c2) {
-    if (J == 0 || row < 0 || row > left_last) {  // no left block there: Dirichlet zero
-      c1 = 0.0;
-      c2 = 0.0;
-      return;
-    }
-    if (!(row >= cbase && row < cbase + cvalid)) {
-      if (next_pending) {  // the batch requested earlier becomes the current one
-        Rc = Rn;
-        cbase = nbase;
-        cvalid = valid_rows(Rc, cbase);
-        next_pending = false;
-      }
-      if (!(row >= cbase && row < cbase + cvalid)) {  // not there yet: ask until it is
-        u64 t0 = 0;
-        bool timing = false;
-        while (true) {
-          cbase = row;
-          Rc = load_granule(left_rec + (long)row * 4 + lane);
-          cvalid = valid_rows(Rc, cbase);
-          if (cvalid > 0) break;
-          if (!timing) {
-            t0 = now_ticks();
-            timing = true;
-          }
-          nap();
-          if (now_ticks() - t0 > kTimeoutTicks || load_word(a.sync + 1) != 0u) {
-            failed = true;
-            break;
-          }
-        }
-        if (failed) {
-          c1 = 0.0;
-          c2 = 0.0;
-          return;
-        }
-      }
-    }
-    const int k = (row - cbase) * 4;
-    const u64 g0 = lane_bits(Rc, k), g1 = lane_bits(Rc, k + 1), g2 = lane_bits(Rc, k + 2), g3 = lane_bits(Rc, k + 3);
+  bool failed = false;
+  auto unpack = [&](u64 R, double& c1, double& c2) {  // false: the record is not complete yet
+    const u64 g0 = lane_bits(R, 0), g1 = lane_bits(R, 1), g2 = lane_bits(R, 2), g3 = lane_bits(R, 3);
     c2 = __builtin_bit_cast(double, (g0 & 0xffffffffull) | (g1 << 32));  // the left block's lane 62
     c1 = __builtin_bit_cast(double, (g2 & 0xffffffffull) | (g3 << 32));  // ... lane 63
+    return ((g0 & g1 & g2 & g3) >> 32) == 1ull;
+  };
+  auto wait_record = [&](int row, double& c1, double& c2) {  // the slow path: ask until the record is complete
+    u64 t0 = 0;
+    bool timing = false;
+    while (true) {
+      const u64 R = load_record(row);
+      if (unpack(R, c1, c2)) return;
+      if (!timing) {
+        t0 = now_ticks();
+        timing = true;
+      }
+      nap();
+      if (now_ticks() - t0 > kTimeoutTicks || load_word(a.sync + 1) != 0u) {
+        failed = true;
+        c1 = 0.0;
+        c2 = 0.0;
+        return;
+      }
+    }
   };
 
-  // pipeline registers: rows i .. i + kDepth of old values
+  // pipeline registers: rows i .. i + kDepth of old values, the records of rows i .. i + 2
   double wn[kDepth + 1], tl[kDepth + 1], fr[kDepth + 1];
 #pragma unroll
   for (int d = 0; d <= kDepth; ++d) load_window(i0 + d, wn[d], tl[d], fr[d]);
+  u64 rq0 = load_record(i0), rq1 = load_record(i0 + 1);
 
-  double prev = 0.0;  // new values of the previous row (this lane's column + 1 there)
-  double c1p, c2p;    // the left block's edge values on the previous row
-  carries_of(i0 - 1, c1p, c2p);
+  double prev = 0.0;           // new values of the previous row (this lane's column + 1 there)
+  double c1p = 0.0, c2p = 0.0;  // the left block's edge values on the previous row
+  if (J > 0 && i0 - 1 >= 0 && i0 - 1 <= left_last) wait_record(i0 - 1, c1p, c2p);
   // e(i) = old value right of this lane's column on row i = s(i - 1): carried from row to row
   double e = from_right(wn[0], lane) + from_left(tl[0], lane);
 
@@ -258,18 +218,13 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     const double sw = wn[1];
     const double s1 = from_right(wn[1], lane);
     const double s = s1 + from_left(tl[1], lane);
-    double lower, upper;
-    if (FIVE) {
-      lower = cN_int * n;
-      upper = fma(cE_int, e, cS_int * s);
-    } else {
-      const double nw = from_left(n, lane) + (lane == 0 ? c2p : 0.0);
-      const double se = from_right(s1, lane) + tl[1];
-      lower = fma(cNW, nw, fma(cN_int, n, cNE * ne));
-      upper = fma(cE_int, e, fma(cSW, sw, fma(cS_int, s, cSE * se)));
+    double nw = 0.0, se = 0.0;
+    if (!FIVE) {
+      nw = from_left(n, lane) + (lane == 0 ? c2p : 0.0);
+      se = from_right(s1, lane) + tl[1];
     }
     const double frow = fr[0];
-    // refill the pipeline while the scan runs
+    // refill the pipelines (no branch around these loads)
 #pragma unroll
     for (int dd = 0; dd < kDepth; ++dd) {
       wn[dd] = wn[dd + 1];
@@ -277,45 +232,40 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       fr[dd] = fr[dd + 1];
     }
     load_window(i + kDepth + 1, wn[kDepth], tl[kDepth], fr[kDepth]);
-    request_next(i);  // the left block's edge values of the rows ahead
+    const u64 rq2 = load_record(i + 2);
 
-    double x;
+    const int j = jmin + lane;
+    const bool valid = j >= 0 && j < nc;
+    double p, qmul;  // x = p + qmul * (value left of lane 0)
     const bool interior = jmin >= 0 && (FIVE ? jmin + 63 <= nc - 1 : (jmin + 63 <= nc - 2 && i < nr - 1));
     if (interior) {
       // every lane is an interior point: constant q, scan of the p part only
-      double p = (ad_int * own + beta * frow - wU * upper - wL * lower) * inv_int;
+      double lower, upper;
+      if (FIVE) {
+        lower = cN_int * n;
+        upper = fma(cE_int, e, cS_int * s);
+      } else {
+        lower = fma(cNW, nw, fma(cN_int, n, cNE * ne));
+        upper = fma(cE_int, e, fma(cSW, sw, fma(cS_int, s, cSE * se)));
+      }
+      p = (ad_int * own + beta * frow - wU * upper - wL * lower) * inv_int;
       p = fma(q0, row_shr<1>(p, lane), p);
       p = fma(q2, row_shr<2>(p, lane), p);
       p = fma(q4, row_shr<4>(p, lane), p);
       p = fma(q8, row_shr<8>(p, lane), p);
       p = fma(Q15, bcast15(p, lane), p);
       p = fma(Q31, bcast31(p, lane), p);
-      double c1, c2;
-      carries_of(i, c1, c2);
-      x = fma(qpow, c1, p);
-      v[(long)i * nc + jmin + lane] = x;
-      c1p = c1;
-      c2p = c2;
+      qmul = qpow;
     } else {
-      const int j = jmin + lane;
-      const bool valid = j >= 0 && j < nc;
       const bool last_col = !FIVE && j == nc - 1, last_row = !FIVE && i == nr - 1;
-      // the centre-column / own-row coefficients change on the last column / row (Galerkin levels): redo the sums
+      // the centre-column / own-row coefficients change on the last column / row (Galerkin levels)
       const double cN = last_col ? a.ccol[0] : cN_int, cS = last_col ? a.ccol[2] : cS_int;
       const double cW = last_row ? a.crow[0] : cW_int, cE = last_row ? a.crow[2] : cE_int;
       const double d = last_row ? (last_col ? d_cor : d_row) : (last_col ? d_col : d_int);
       const double invd = last_row ? (last_col ? inv_cor : inv_row) : (last_col ? inv_col : inv_int);
-      double lo2, up2;
-      if (FIVE) {
-        lo2 = lower;
-        up2 = upper;
-      } else {
-        const double nw = from_left(n, lane) + (lane == 0 ? c2p : 0.0);
-        const double se = from_right(s1, lane) + tl[0];  // (tl was shifted above: tl[0] now is the row below's)
-        lo2 = fma(cNW, nw, fma(cN, n, cNE * ne));
-        up2 = fma(cE, e, fma(cSW, sw, fma(cS, s, cSE * se)));
-      }
-      double p = (alpha * d * own + beta * frow - wU * up2 - wL * lo2) * invd;
+      const double lower = fma(cNW, nw, fma(cN, n, cNE * ne));
+      const double upper = fma(cE, e, fma(cSW, sw, fma(cS, s, cSE * se)));
+      p = (alpha * d * own + beta * frow - wU * upper - wL * lower) * invd;
       double qq = -wL * cW * invd;
       if (!valid) {
         p = 0.0;
@@ -339,13 +289,15 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       MGCMT_LEX_STEP(bcast15, (lane & 16) != 0)
       MGCMT_LEX_STEP(bcast31, lane >= 32)
 #undef MGCMT_LEX_STEP
-      double c1, c2;
-      carries_of(i, c1, c2);
-      x = valid ? fma(qq, c1, p) : 0.0;
-      if (valid) v[(long)i * nc + j] = x;
-      c1p = c1;
-      c2p = c2;
+      qmul = qq;
     }
+    // the value left of lane 0 on this row: the left block's lane 63 (its record was requested two rows ago)
+    double c1 = 0.0, c2 = 0.0;
+    if (J > 0 && i <= left_last) {
+      if (!unpack(rq0, c1, c2)) wait_record(i, c1, c2);
+    }
+    const double x = valid ? fma(qmul, c1, p) : 0.0;
+    if (valid) v[(long)i * nc + j] = x;
     if (publish && lane >= 62) {  // {tag, half} granules of lanes 62 / 63: the right block's NW / N / W values
       const u64 bits = __builtin_bit_cast(u64, x);
       u64* rec = my_rec + (long)i * 4 + (lane - 62) * 2;
@@ -353,7 +305,11 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       store_granule(rec + 1, (1ull << 32) | (bits >> 32));
     }
     prev = x;
+    c1p = c1;
+    c2p = c2;
     e = s;  // the row below becomes the own row
+    rq0 = rq1;
+    rq1 = rq2;
     if (failed) break;
   }
   if (failed && lane == 0) store_word(a.sync + 1, 1u);  // tell the host and release everyone behind this block
