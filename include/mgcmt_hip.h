@@ -218,6 +218,30 @@ int mgcmt_allreduce_sum(mgcmt_plan* plan, double* host_inout, int n, void* strea
 int mgcmt_sharded_vcycle(mgcmt_plan* plan, mgcmt_plan* coarse, int nu1, int nu2, int nu_coarse, int kind, double omega,
                          int flags, void* stream);
 
+/* ---- general sparse, complex128 operators -------------------------------------------------------
+ * The k.p Hamiltonians of ThesisProblem.py:38-40,80,101 / PotWellSolver.py:54-233: an arbitrary square CSR matrix of
+ * complex numbers (values = interleaved re, im), cycled as ONE 1-D grid of its full length with the reference's 1-D
+ * transfer operators (MGCMTStencilMaker.py:27-78).  The plan builds the Galerkin hierarchy R*A*P (MGCMTSolver.py:318)
+ * on the device; vectors are complex (interleaved), slots V, F, T as for mgcmt_plan.  n and lowest are powers of two,
+ * lowest <= 64 (the coarsest level is solved by a dense LU with row pivoting, :305-308). */
+typedef struct mgcmt_csr_plan mgcmt_csr_plan;
+int mgcmt_csr_plan_create(int device, int64_t n, int64_t lowest, const int64_t* indptr, const int32_t* indices, const double* values,
+                          mgcmt_csr_plan** out);
+int mgcmt_csr_plan_destroy(mgcmt_csr_plan* plan);
+int mgcmt_csr_num_levels(const mgcmt_csr_plan* plan, int* levels);
+/* rows, entries and the chunk length of the lexicographic sweeps (rows solved together as a first-order recurrence) */
+int mgcmt_csr_level_info(const mgcmt_csr_plan* plan, int level, int64_t* n, int64_t* nnz, int32_t* lex_chunk_rows);
+/* host copy of a level's matrix (indptr[n+1], indices[nnz], values[2*nnz]): what R*A*P gave on the device */
+int mgcmt_csr_get_matrix(const mgcmt_csr_plan* plan, int level, int64_t* indptr, int32_t* indices, double* values);
+int mgcmt_csr_upload(mgcmt_csr_plan* plan, int level, int slot, const double* re_im, int64_t count, void* stream);
+int mgcmt_csr_download(mgcmt_csr_plan* plan, int level, int slot, double* re_im, int64_t count, void* stream);
+/* dst <- (A_level - shift I) src */
+int mgcmt_csr_apply(mgcmt_csr_plan* plan, int level, int src_slot, int dst_slot, double shift, void* stream);
+/* nu sweeps of MGCMT_WJACOBI / MGCMT_GS_LEX / MGCMT_SOR_LEX on V, F of `level` for (A_level - shift I) */
+int mgcmt_csr_smooth(mgcmt_csr_plan* plan, int level, int kind, int nu, double omega, double shift, void* stream);
+/* one V-cycle (MGCMTSolver.py:281-329) from level 0; nu_coarse: sweeps below the top level (the reference: 4, :320) */
+int mgcmt_csr_vcycle(mgcmt_csr_plan* plan, int nu1, int nu2, int nu_coarse, int kind, double omega, double shift, void* stream);
+
 /* plan options: MGCMT_OPT_FUSED (default 1) selects the fused row-streaming kernels on large constant-
  * coefficient levels; 0 forces the one-launch-per-operation kernels everywhere (A/B checks) */
 typedef enum mgcmt_option {

@@ -103,6 +103,16 @@ _SIGNATURES = {
     "mgcmt_gather_coarse": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mgcmt_allreduce_sum": (c_int, [c_void_p, _dp, c_int, c_void_p]),
     "mgcmt_sharded_vcycle": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p]),
+    "mgcmt_csr_plan_create": (c_int, [c_int, c_int64, c_int64, POINTER(c_int64), POINTER(c_int32), _dp, POINTER(c_void_p)]),
+    "mgcmt_csr_plan_destroy": (c_int, [c_void_p]),
+    "mgcmt_csr_num_levels": (c_int, [c_void_p, POINTER(c_int)]),
+    "mgcmt_csr_level_info": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
+    "mgcmt_csr_get_matrix": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int32), _dp]),
+    "mgcmt_csr_upload": (c_int, [c_void_p, c_int, c_int, _dp, c_int64, c_void_p]),
+    "mgcmt_csr_download": (c_int, [c_void_p, c_int, c_int, _dp, c_int64, c_void_p]),
+    "mgcmt_csr_apply": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p]),
+    "mgcmt_csr_smooth": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_double, c_void_p]),
+    "mgcmt_csr_vcycle": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_void_p]),
     "mgcmt_plan_set_option": (c_int, [c_void_p, c_int, c_int]),
     "mgcmt_bandwidth_probe": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _dp, c_void_p]),
     "mgcmt_time_smoother": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, _dp, c_void_p]),

@@ -425,9 +425,13 @@ int mgcmt_csr_plan_create(int device, int64_t n, int64_t lowest, const int64_t* 
                           mgcmt_csr_plan** out) {
   if (!indptr || !indices || !values || !out) return fail(MGCMT_ERR_INVALID, "null argument");
   *out = nullptr;
-  if (n < 2 || (n & (n - 1)) || lowest < 2 || (lowest & (lowest - 1)) || lowest > n)
-    return fail(MGCMT_ERR_INVALID, "n and lowest must be powers of two with 2 <= lowest <= n");
-  if (lowest > kDenseMax) return fail(MGCMT_ERR_UNSUPPORTED, "general sparse operators: the coarsest level may have at most 64 unknowns");
+  if (lowest != n) {  // (a single level — smoothing and operator application only — may have any size)
+    if (n < 2 || (n & (n - 1)) || lowest < 2 || (lowest & (lowest - 1)) || lowest > n)
+      return fail(MGCMT_ERR_INVALID, "n and lowest must be powers of two with 2 <= lowest <= n");
+    if (lowest > kDenseMax) return fail(MGCMT_ERR_UNSUPPORTED, "general sparse operators: the coarsest level may have at most 64 unknowns");
+  } else if (n < 1) {
+    return fail(MGCMT_ERR_INVALID, "empty matrix");
+  }
   if (n > (1L << 30)) return fail(MGCMT_ERR_UNSUPPORTED, "matrix too large");
   MG_HIP(hipSetDevice(device));
   mgcmt_csr_plan* p = new mgcmt_csr_plan();
@@ -596,6 +600,7 @@ int mgcmt_csr_vcycle(mgcmt_csr_plan* p, int nu1, int nu2, int nu_coarse, int kin
   }
   {
     CsrLevel& L = p->levels[last];
+    if (L.n > kDenseMax) return fail(MGCMT_ERR_UNSUPPORTED, "general sparse operators: the coarsest level may have at most 64 unknowns");
     hipLaunchKernelGGL(k_csr_dense_solve, dim3(1), dim3(256), 0, s, kcsr(L), shift, L.vec[MGCMT_SLOT_F], L.vec[MGCMT_SLOT_V]);
   }
   for (int l = last - 1; l >= 0; --l) {

@@ -30,7 +30,9 @@ namespace mgcmt {
 
 namespace {
 
-constexpr int kDepth = 3;   // rows of old values in flight ahead of the row being processed
+constexpr int kDepth = 5;   // rows of old values in flight ahead of the row being processed
+constexpr int kAhead = 6;   // rows by which the left block's edge records are requested ahead of their use (their stores
+                            // are write-through, so the loads come from memory, not from L2: 1-2 us)
 
 struct LexWaveArgs {
   double* v;
@@ -196,11 +198,13 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     }
   };
 
-  // pipeline registers: rows i .. i + kDepth of old values, the records of rows i .. i + 2
+  // pipeline registers: rows i .. i + kDepth of old values, the records of rows i .. i + kAhead - 1
   double wn[kDepth + 1], tl[kDepth + 1], fr[kDepth + 1];
 #pragma unroll
   for (int d = 0; d <= kDepth; ++d) load_window(i0 + d, wn[d], tl[d], fr[d]);
-  u64 rq0 = load_record(i0), rq1 = load_record(i0 + 1);
+  u64 rq[kAhead];
+#pragma unroll
+  for (int d = 0; d < kAhead; ++d) rq[d] = load_record(i0 + d);
 
   double prev = 0.0;           // new values of the previous row (this lane's column + 1 there)
   double c1p = 0.0, c2p = 0.0;  // the left block's edge values on the previous row
@@ -232,7 +236,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       fr[dd] = fr[dd + 1];
     }
     load_window(i + kDepth + 1, wn[kDepth], tl[kDepth], fr[kDepth]);
-    const u64 rq2 = load_record(i + 2);
+    const u64 rq_new = load_record(i + kAhead);
 
     const int j = jmin + lane;
     const bool valid = j >= 0 && j < nc;
@@ -291,10 +295,10 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
 #undef MGCMT_LEX_STEP
       qmul = qq;
     }
-    // the value left of lane 0 on this row: the left block's lane 63 (its record was requested two rows ago)
+    // the value left of lane 0 on this row: the left block's lane 63 (its record was requested kAhead rows ago)
     double c1 = 0.0, c2 = 0.0;
     if (J > 0 && i <= left_last) {
-      if (!unpack(rq0, c1, c2)) wait_record(i, c1, c2);
+      if (!unpack(rq[0], c1, c2)) wait_record(i, c1, c2);
     }
     const double x = valid ? fma(qmul, c1, p) : 0.0;
     if (valid) v[(long)i * nc + j] = x;
@@ -308,8 +312,9 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     c1p = c1;
     c2p = c2;
     e = s;  // the row below becomes the own row
-    rq0 = rq1;
-    rq1 = rq2;
+#pragma unroll
+    for (int d = 0; d + 1 < kAhead; ++d) rq[d] = rq[d + 1];
+    rq[kAhead - 1] = rq_new;
     if (failed) break;
   }
   if (failed && lane == 0) store_word(a.sync + 1, 1u);  // tell the host and release everyone behind this block

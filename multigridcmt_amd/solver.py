@@ -14,7 +14,7 @@ import scipy.linalg
 
 from . import _lib
 from ._lib import GS_LEX, GS_MC, OP_A, OP_M, SLOT_F, SLOT_T, SLOT_V, SLOT_W, SOR_LEX, WJACOBI
-from .operators import StructuredOperator, laplacian_operator, recognise, tag_structured
+from .operators import StructuredOperator, UnrecognisedOperator, laplacian_operator, recognise, tag_structured
 from .plan import get_plan
 from .processor import MGCMTProcessor
 from .stencil_maker import MGCMTStencilMaker
@@ -49,13 +49,46 @@ class MGCMTSolver:
     # ------------------------------------------------------------------------------------------
     def _smooth(self, v0, f, A, kind, nu, omega, dimension=None):
         n = len(v0)
-        op = recognise(A, dimension)
+        try:
+            op = recognise(A, dimension)
+        except UnrecognisedOperator:
+            if dimension == "2d":
+                raise
+            return self._smooth_general(v0, f, A, kind, nu, omega)
         plan = get_plan(op, op.g, nvec=1)
         plan.set_shifts([0.0])
         plan.upload(0, SLOT_V, 0, np.asarray(v0, dtype=np.float64).reshape(-1))
         plan.upload(0, SLOT_F, 0, np.asarray(f, dtype=np.float64).reshape(-1))
         plan.smooth(0, kind, int(nu), omega=float(omega), k=1)
         return plan.download(0, SLOT_V, 0).reshape(n, 1)
+
+    # -- general sparse / complex operators: the k.p Hamiltonians of ThesisProblem.py:38-40,80,101 ----
+    def _smooth_general(self, v0, f, A, kind, nu, omega):
+        from .general import get_csr_plan, real_if_real
+        n = len(v0)
+        plan = get_csr_plan(A, n)                       # one level: smoothing only
+        plan.upload(0, SLOT_V, v0)
+        plan.upload(0, SLOT_F, f)
+        plan.smooth(0, kind, int(nu), omega=float(omega))
+        return real_if_real(plan.download(0, SLOT_V), v0, f, A).reshape(n, 1)
+
+    def _vcycle_general(self, v0, f, A, kind, omega, nu1, nu2, nu_coarse, shift, lowest_level):
+        """vcycle (MGCMTSolver.py:281-329) for an operator ``recognise`` cannot map — any square scipy.sparse matrix, real
+        or complex, cycled as ONE 1-D grid of its full length (ThesisProblem.py:101: a complex 4n x 4n block matrix,
+        smoother=solver.gseidel, lowest_level=2**5).  Galerkin hierarchy, smoothing, transfers and the coarsest solve
+        run on the GPU (csrc/csr.hip); the result is complex when an input is."""
+        from .general import get_csr_plan, real_if_real
+        if kind is None:
+            raise NotImplementedError("general sparse operators take this class's wjacobi / gseidel / sor")
+        if np.iscomplexobj(shift):
+            raise NotImplementedError("complex shifts are not supported (the reference's are real guesses of eigenvalues)")
+        n = len(v0)
+        plan = get_csr_plan(A, int(lowest_level))
+        plan.upload(0, SLOT_V, v0)
+        plan.upload(0, SLOT_F, f)
+        plan.vcycle(nu1, nu2, kind, omega=omega, nu_coarse=nu_coarse, shift=float(shift))
+        v = real_if_real(plan.download(0, SLOT_V), v0, f, A)
+        return v.reshape(n, 1) if n == lowest_level else v
 
     def wjacobi(self, v0, f, A, nu=4, omega=2. / 3.):
         """MGCMTSolver.py:182-208 — v <- (I - w D^-1 A) v + w D^-1 f, nu times; returns (n, 1)."""
@@ -226,7 +259,12 @@ class MGCMTSolver:
         if not self._check_grid(g, lowest_level):
             return None
         g = int(g)
-        op = recognise(A, dimension)
+        try:
+            op = recognise(A, dimension)
+        except UnrecognisedOperator:
+            if dimension != "1d":
+                raise
+            return self._vcycle_general(v0, f, A, kind, omega, int(nu1), int(nu2), int(nu_coarse), shift, int(lowest_level))
         plan = get_plan(op, int(lowest_level), nvec=1)
         plan.set_shifts([float(shift)])
         plan.upload(0, SLOT_V, 0, np.asarray(v0, dtype=np.float64).reshape(-1))

@@ -313,6 +313,37 @@ def main():
         mgs["V_final_" + placement] = V.copy()
     save("driver_1dpot_mgs", **mgs)
 
+    # ---- the reference's vcycle on its own k.p Hamiltonian (ThesisProblem.py:26-40,62-101) ----------
+    # 4-band GaAs well confined along z, complex 4n x 4n block matrix cycled as ONE 1-D grid of length 4n, guesses
+    # from 32 points per band, lowest_level = 2**5, smoother = solver.gseidel — at n = 64 and off the gamma point
+    # (k = 0.5), where the off-diagonal blocks are non-zero and imaginary
+    PotWellSolver, Compound, GaAsValues, PotentialWell = ref_loader.load_kp_model()
+    kp = {}
+    pws = PotWellSolver(Compound(GaAsValues), PotentialWell("z"), 4)
+    for tag, npts, kpoint in (("n64_k0.5", 64, 0.5), ("n128_k0", 128, 0.0)):
+        pws.setGridPoints(npts)
+        pws.setXRange(-1, 1) if hasattr(pws, "setXRange") else None
+        pws.setDense(0)
+        Hkp = sp.csr_matrix(pws.makeMatrix(kpoint))
+        Hkp.sort_indices()
+        N = Hkp.shape[0]
+        pws.setGridPoints(32)
+        bad = sp.csr_matrix(pws.makeMatrix(kpoint))
+        guess = np.sort(sla.eigsh(bad, k=3, which="SM", tol=1e-12)[0])
+        rng = np.random.RandomState(len(tag))
+        fk = rng.rand(N) + 1j * rng.rand(N)
+        kp[tag + "_data"], kp[tag + "_indices"], kp[tag + "_indptr"] = Hkp.data, Hkp.indices, Hkp.indptr
+        kp[tag + "_f"], kp[tag + "_shift"] = fk, np.array(guess[0])
+        for name, smo in (("gs", solver.gseidel), ("wj", solver.wjacobi), ("sor", lambda v, f, A, nu=4: solver.sor(v, f, A, nu=nu, omega=1.2))):
+            kp["%s_vcycle_%s" % (tag, name)] = np.array(solver.vcycle(
+                np.zeros((N, 1), dtype=complex), fk.copy().reshape(N, 1), Hkp, sm, shift=guess[0], lowest_level=2 ** 5,
+                smoother=smo)).ravel()
+        kp[tag + "_gseidel3"] = np.array(solver.gseidel(fk.copy().reshape(N, 1) * 0.5, fk.copy().reshape(N, 1), Hkp, nu=3)).ravel()
+        kp[tag + "_wjacobi3"] = np.array(solver.wjacobi(fk.copy().reshape(N, 1) * 0.5, fk.copy().reshape(N, 1), Hkp, nu=3)).ravel()
+        R1, P1 = sm.restriction(N, N // 2), sm.interpolation(N // 2, N)
+        kp[tag + "_rap_dense"] = (R1 * Hkp * P1).toarray()
+    save("kp_well", **kp)
+
     # ---- BASELINE config 5 at a size the reference can run: square-well Hamiltonian on a 2-D grid -------------------
     # H = -laplacian/pi^2 + diag(V), V = depth outside the square [lo,hi)^2 (the potential of PotWellSolver.py:150-153
     # carried to two dimensions), through the reference's own vcycle (2-D transfers) and rqmin (RQMin.py:18-27)

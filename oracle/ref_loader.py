@@ -85,3 +85,37 @@ def load_reference():
     return (_CACHE["MGCMTSolver"].MGCMTSolver,
             _CACHE["MGCMTStencilMaker"].MGCMTStencilMaker,
             _CACHE["MGCMTProcessor"].MGCMTProcessor)
+
+
+def load_kp_model():
+    """(PotWellSolver, Compound, GaAsValues, PotentialWell) of the reference's k.p model (PotWellSolver.py,
+    baseCompounds.py, PotentialWell.py) for fixtures of SURVEY §8 (f)2.  Two mechanical shims, both for the interpreter
+    and NumPy in this container rather than for the model: ``math`` is made visible (the module relied on
+    ``from pylab import *`` leaking it, PotWellSolver.py:2,9) and the well boundaries, which the reference computes with
+    np.floor / np.ceil and then uses as slice bounds (:28-32,41-43,151-152), are cast to int."""
+    import builtins
+    import math
+    if "PotWellSolver" not in _CACHE:
+        builtins.math = math
+        load_reference()
+        saved = {m: sys.modules.get(m) for m in ("baseCompounds", "PotentialWell", "PotWellSolver")}
+        try:
+            for m in ("baseCompounds", "PotentialWell", "PotWellSolver"):
+                _CACHE[m] = _load_one(m, os.path.join(REFERENCE_ROOT, m + ".py"))
+        finally:
+            for m, old in saved.items():
+                if old is None:
+                    sys.modules.pop(m, None)
+                else:
+                    sys.modules[m] = old
+        cls = _CACHE["PotWellSolver"].PotWellSolver
+        original = cls.setParameters
+
+        def set_parameters(self, *args, **kwargs):
+            original(self, *args, **kwargs)
+            self.potWellBoundary1 = int(self.potWellBoundary1)
+            self.potWellBoundary2 = int(self.potWellBoundary2)
+
+        cls.setParameters = set_parameters
+    return (_CACHE["PotWellSolver"].PotWellSolver, _CACHE["baseCompounds"].Compound, _CACHE["baseCompounds"].GaAsValues,
+            _CACHE["PotentialWell"].PotentialWell)

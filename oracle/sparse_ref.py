@@ -145,7 +145,8 @@ class RefProcessor:
 # ----------------------------------------------------------------------------------------------
 
 def _col(x):
-    return np.asarray(x, dtype=float).reshape(-1).copy()
+    a = np.asarray(x)
+    return a.astype(complex if np.iscomplexobj(a) else float).reshape(-1).copy()
 
 
 def colour_classes(n, dimension):

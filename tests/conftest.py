@@ -21,7 +21,9 @@ def load_golden(name):
 
 
 def rel_err(a, b):
-    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    a, b = np.asarray(a), np.asarray(b)
+    kind = complex if (np.iscomplexobj(a) or np.iscomplexobj(b)) else float
+    a, b = a.astype(kind), b.astype(kind)
     return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
 
 
