@@ -8,22 +8,19 @@ import numpy as np
 
 
 def _init_group(backend, rank, world, local, on_gpu):
-    """torch.distributed is the control plane (rendezvous, barriers, the maximum of the rank times); the store it
-    rendezvouses through also carries the RCCL communicator id of the data path."""
-    import datetime
+    """torch.distributed is the control plane (rendezvous through the launcher's env:// variables — under torchrun the
+    agent's own store —, barriers, the maximum of the rank times); it also carries the RCCL communicator id of the data
+    path from rank 0 to the others."""
     import torch
     import torch.distributed as dist
-    store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, rank == 0,
-                          timeout=datetime.timedelta(seconds=300))
     if on_gpu:
         torch.cuda.set_device(local)
         try:
-            dist.init_process_group(backend, store=store, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         except TypeError:                                   # older signature without device_id
-            dist.init_process_group(backend, store=store, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
-        dist.init_process_group(backend, store=store, rank=rank, world_size=world)
-    return store
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
 
 def run(args, backend="nccl", on_gpu=True):
@@ -40,13 +37,13 @@ def run(args, backend="nccl", on_gpu=True):
     os.environ.setdefault("MASTER_PORT", "29533")
     local = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    store = _init_group(backend, rank, world, local, on_gpu)
+    _init_group(backend, rank, world, local, on_gpu)
     transport = getattr(args, "transport", "rccl") if on_gpu else "torch"
     uid = None
     if transport == "rccl":
-        if rank == 0:
-            store.set("mgcmt_rccl_id", rccl_unique_id())
-        uid = bytes(store.get("mgcmt_rccl_id"))
+        box = [rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = bytes(box[0])
     g = args.grid
     kind = _lib.WJACOBI if args.smoother == "wjacobi" else _lib.GS_MC
     omega = 2.0 / 3.0 if args.smoother == "wjacobi" else 1.0

@@ -1,0 +1,117 @@
+"""Turn one run of scripts/gpu_r02_profiles.sh (gpurun_out/*_<tag>*) into the tracked summaries under profiles/:
+
+  pmc_traffic.json                  HBM bytes per launch of the fused fine-level pass (what bench.py reports as `traffic`),
+                                    with `_source` = where the numbers came from
+  <prefix>_pmc_traffic_detail.json  FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md "HBM") / WRITE_SIZE per kernel
+  <prefix>_kernel_table.md          per kernel of the 16384^2 cycles: launches, average time, VGPRs, waves/SIMD the
+                                    registers allow, VALU-active share of the wave cycles, HBM bytes and the rate they imply
+  <prefix>_{wjacobi,rb,cfg2,cfg5}_kernel_stats.csv   rocprofv3 --stats tables
+usage: collect_profiles_r02.py <tag> <out-prefix> [commit]"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, prefix = sys.argv[1], sys.argv[2]
+commit = sys.argv[3] if len(sys.argv) > 3 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+out = os.path.join(ROOT, "profiles")
+g = os.path.join(ROOT, "gpurun_out")
+n = 16384
+
+
+def latest(pattern):
+    files = sorted(glob.glob(os.path.join(g, pattern), recursive=True), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def short(name):
+    name = name.replace("void ", "").replace("mgcmt::fused::", "").replace("mgcmt::(anonymous namespace)::", "").replace("mgcmt::", "")
+    return name.split("(")[0]
+
+
+def waves_per_simd(vgprs):
+    alloc = -(-int(vgprs) // 8) * 8
+    return max(1, min(8, 512 // max(alloc, 1)))
+
+
+table_rows, detail, traffic = [], {}, {}
+for sm in ("wjacobi", "rb"):
+    per = {}
+    trace = latest("prof_%s_%s/**/*kernel_trace.csv" % (tag, sm))
+    if trace:
+        for r in csv.DictReader(open(trace)):
+            k = per.setdefault(r["Kernel_Name"], {"calls": 0, "ns": 0.0, "vgpr": r.get("VGPR_Count") or r.get("Arch_VGPR_Count"), "sgpr": r.get("SGPR_Count"),
+                                                  "lds": r.get("LDS_Block_Size")})
+            k["calls"] += 1
+            k["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    for counter_dir, counters in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]),
+                                  ("SQ", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAIT_ANY",
+                                          "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"])):
+        f = latest("pmc_%s_%s_%s/**/*counter_collection.csv" % (tag, sm, counter_dir))
+        if not f:
+            continue
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] in counters:
+                a = acc.setdefault((r["Kernel_Name"], r["Counter_Name"]), [0.0, 0])
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+        for (kname, cname), (tot, cnt) in acc.items():
+            per.setdefault(kname, {"calls": 0, "ns": 0.0, "vgpr": None, "sgpr": None, "lds": None})[cname] = tot / cnt
+    for kname, k in sorted(per.items(), key=lambda kv: -kv[1]["ns"]):
+        if not k["calls"] or "k_probe" in kname or "rocclr" in kname:
+            continue
+        avg_us = k["ns"] / k["calls"] / 1e3
+        fetch = k.get("FETCH_SIZE")
+        write = k.get("WRITE_SIZE")
+        hbm = (fetch * 2048 + write * 1024) if fetch is not None and write is not None else None
+        valu = (100.0 * k["SQ_ACTIVE_INST_VALU"] / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None
+        wait = (100.0 * k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None
+        table_rows.append((sm, short(kname), k["calls"], avg_us, k["vgpr"], waves_per_simd(k["vgpr"]) if k["vgpr"] else None, valu, wait,
+                           hbm, (hbm / (avg_us * 1e-6) / 1e12) if hbm else None))
+        if hbm is not None:
+            detail["%s_%d %s" % (sm, n, short(kname))] = {"avg_us": avg_us, "FETCH_SIZE_KB_avg": fetch, "WRITE_SIZE_KB_avg": write,
+                                                          "fetch_bytes_corrected_x2": fetch * 2048, "write_bytes": write * 1024, "hbm_bytes": hbm}
+        want = "k_fused<Op5, %d, 2, 0>" % (0 if sm == "wjacobi" else 1)
+        if short(kname) == want and hbm is not None:
+            traffic["%s_%d" % (sm, n)] = hbm
+    stats = latest("prof_%s_%s/**/*kernel_stats.csv" % (tag, sm))
+    if stats:
+        shutil.copy(stats, os.path.join(out, "%s_%s_%d_kernel_stats.csv" % (prefix, sm, n)))
+    log = os.path.join(g, "prof_%s_%s.log" % (tag, sm))
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith('{"metric"')]
+        if lines:
+            open(os.path.join(out, "%s_bench_under_rocprof_%s.json" % (prefix, sm)), "w").write(lines[-1])
+for cfg in ("cfg2", "cfg5"):
+    stats = latest("prof_%s_%s/**/*kernel_stats.csv" % (tag, cfg))
+    if stats:
+        shutil.copy(stats, os.path.join(out, "%s_%s_kernel_stats.csv" % (prefix, cfg)))
+    log = os.path.join(g, "prof_%s_%s.log" % (tag, cfg))
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{")]
+        if lines:
+            open(os.path.join(out, "%s_%s_bench_under_rocprof.json" % (prefix, cfg)), "w").write("".join(lines))
+if traffic:
+    traffic["_source"] = {"file": "profiles/pmc_traffic.json", "commit": commit, "run_tag": tag,
+                          "kernel": "k_fused<Op5,{0|1},2,0> (fused fine-level pass, 2 sweeps per launch)",
+                          "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --smoother <sm> (scripts/gpu_r02_profiles.sh)",
+                          "correction": "FETCH_SIZE x 2 (gfx950 tallies 128-byte requests of 16-byte streams at 64 B, MI355X_MICROARCH.md HBM), counters in KB"}
+    json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    json.dump(detail, open(os.path.join(out, "%s_pmc_traffic_detail.json" % prefix), "w"), indent=1)
+with open(os.path.join(out, "%s_kernel_table.md" % prefix), "w") as fh:
+    fh.write("# Per-kernel table of the 16384^2 V(2,2) cycles (run tag %s, commit %s)\n\n" % (tag, commit))
+    fh.write("rocprofv3 kernel trace + PMC passes of `bench.py --smoother <sm>` (scripts/gpu_r02_profiles.sh).  waves/SIMD = what the VGPR\n"
+             "allocation admits (MI355X_MICROARCH.md, Register files); VALU %% = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, wait %% = SQ_WAIT_ANY /\n"
+             "SQ_WAVE_CYCLES (both per wave); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE per launch; TB/s = those bytes / average launch time.\n"
+             "Template arguments of k_fused: <operator policy, smoother (0 Jacobi, 1 red-black, 2 four-colour), sweeps, flags (1 prolong, 2 restrict,\n4 zero-in, 8 no-store, 16/32 recomputed sweeps)>.\n\n")
+    fh.write("| cycle | kernel | launches | avg us | VGPRs | waves/SIMD | VALU % | wait % | HBM MB/launch | TB/s |\n|---|---|---|---|---|---|---|---|---|---|\n")
+    for sm, k, calls, us, vg, wps, valu, wait, hbm, rate in table_rows:
+        fh.write("| %s | `%s` | %d | %.1f | %s | %s | %s | %s | %s | %s |\n" % (
+            sm, k, calls, us, vg or "", wps or "", "%.0f" % valu if valu is not None else "", "%.0f" % wait if wait is not None else "",
+            "%.1f" % (hbm / 1e6) if hbm else "", "%.2f" % rate if rate else ""))
+print(open(os.path.join(out, "%s_kernel_table.md" % prefix)).read())

@@ -120,3 +120,27 @@ def test_multi_rank_bench_line(tmp_path):
         assert key in out, key
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong" and out["config"]["strip_levels"] == 2
     assert out["value"] > 0 and abs(out["value"] - 512 * 512 * 4 * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6) < 1e-6 * out["value"]
+
+
+def test_bench_under_torchrun(tmp_path):
+    """The round driver's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`) with a rank program that swaps RCCL
+    for gloo and the GPU for the emulated kernels: rendezvous through the launcher's agent store, defaults of the
+    multi-GPU leg (grid / smoother overridden to CPU-sized ones), ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    import build_emu
+    build_emu.build()                                 # once, before two ranks race to build it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--grid", "512", "--switch-grid", "128"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["smoother"] == "rb" and line["config"]["grid"] == 512
+    assert line["scaling"] == "strong" and line["value"] > 0
