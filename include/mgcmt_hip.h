@@ -195,7 +195,8 @@ int mgcmt_comm_destroy(mgcmt_plan* plan);
 typedef enum mgcmt_comm_option {
   MGCMT_COMM_OPT_OVERLAP = 0, /* default 1 (RCCL): the exchange of a pass's boundary rows runs on a second stream beside
                                  the launch that produces the interior rows */
-  MGCMT_COMM_OPT_SPLIT = 1,   /* default 1: boundary rows are produced by their own launches first */
+  MGCMT_COMM_OPT_SPLIT = 1,   /* default 1: boundary rows are produced by their own launches first on strips of >= 2^22 points (where the
+                                 exchange they take off the critical path outweighs two more launches); 2: on every strip; 0: never */
   MGCMT_COMM_OPT_SELF_RING = 2 /* default 0; 1 on a ONE-rank communicator: the rank acts as its own upper and lower neighbour in
                                  every exchange of a cycle (the rows it receives are never read): the split launches, the
                                  transport and the stream overlap run for real on one GPU */

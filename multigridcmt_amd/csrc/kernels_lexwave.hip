@@ -30,8 +30,8 @@ namespace mgcmt {
 
 namespace {
 
-constexpr int kDepth = 5;   // rows of old values in flight ahead of the row being processed
-constexpr int kAhead = 6;   // rows by which the left block's edge records are requested ahead of their use (their stores
+constexpr int kDepth = 3;   // rows of old values in flight ahead of the row being processed
+constexpr int kAhead = kDepth + 1;   // rows by which the left block's edge records are requested ahead of their use (their stores
                             // are write-through, so the loads come from memory, not from L2: 1-2 us)
 
 struct LexWaveArgs {
@@ -99,9 +99,20 @@ __device__ __forceinline__ u64 now_ticks() { return 0; }
 __device__ __forceinline__ void nap() {}
 #endif
 
+template <bool B>
+struct Checked {
+  static constexpr bool value = B;
+};
+template <int N>
+struct Int {
+  static constexpr int value = N;
+};
+
 constexpr u64 kTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz counter: a stuck pipeline gives up
 
-template <bool FIVE>
+// FIVE: constant 5-point operator (no corner terms, no special last row / column); OWN: the sweep uses the point's own
+// old value (alpha != 0: the homogeneous SOR recurrence)
+template <bool FIVE, bool OWN>
 __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   const int lane = threadIdx.x;
   // block number = order of arrival: whoever this block waits for has started before it
@@ -120,6 +131,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   const int i1 = J * 64 + 63 < nr - 1 ? J * 64 + 63 : nr - 1;    // last one
   const int left_last = J > 0 ? (J * 64 - 1 < nr - 1 ? J * 64 - 1 : nr - 1) : -1;  // last row the left block works on
   const bool publish = J + 1 < a.nblocks;
+  unsigned* const err_word = a.sync + 1;  // (locals, not `a`, inside the lambdas: the argument block then stays out of memory)
   if (i0 > i1) return;  // (cannot happen for nblocks = ceil((nr + nc - 1) / 64); kept as a guard)
 
   const double mu = a.shifts[q];
@@ -127,11 +139,13 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // coefficient classes: interior, last column, last row, corner
   const double cNW = a.c[0][0], cNE = a.c[0][2], cSW = a.c[2][0], cSE = a.c[2][2];
   const double cN_int = a.c[0][1], cS_int = a.c[2][1], cW_int = a.c[1][0], cE_int = a.c[1][2];
+  const double cN_col = a.ccol[0], cS_col = a.ccol[2], cW_row = a.crow[0], cE_row = a.crow[2];
   const double d_int = a.c[1][1] - mu, d_col = a.ccol[1] - mu, d_row = a.crow[1] - mu, d_cor = a.ccorner - mu;
   const double inv_int = 1.0 / d_int, inv_col = 1.0 / d_col, inv_row = 1.0 / d_row, inv_cor = 1.0 / d_cor;
-  const double ad_int = alpha * d_int;
-  // rows whose 64 columns are all interior points: the recurrence has ONE q, so only the p part of the maps is scanned;
-  // the products of q it needs are per-lane constants
+  // rows whose 64 columns are all interior points: p = kF f + kE e + kS s + ... with these constants, ONE q, so only the
+  // p part of the maps is scanned; the products of q the scan needs are per-lane constants
+  const double kF = beta * inv_int, kO = alpha, kE = -wU * cE_int * inv_int, kS = -wU * cS_int * inv_int, kN = -wL * cN_int * inv_int;
+  const double kSW = -wU * cSW * inv_int, kSE = -wU * cSE * inv_int, kNW = -wL * cNW * inv_int, kNE = -wL * cNE * inv_int;
   const double q0 = -wL * cW_int * inv_int;
   const double q2 = q0 * q0, q4 = q2 * q2, q8 = q4 * q4;
   double qpow = q0, Q15 = 0.0, Q31 = 0.0;  // q0^(lane + 1); q0^((lane & 15) + 1) on the second 16 of every 32; q0^(lane - 31) on the upper 32
@@ -145,40 +159,62 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     }
   }
 
-  // old values: window of row r = v[r][J*64 + lane - r] (this block's columns on that row); T = the two columns to its
-  // right, held by lanes 62 (first) and 63 (second), zero elsewhere.  Rows nr.. are the zero halo rows; columns outside
-  // the grid read as zero.  The loads are UNCONDITIONAL (clamped addresses, values masked afterwards) and there is no
-  // branch around any memory instruction of the row loop, so the compiler counts the loads in flight exactly
-  // (s_waitcnt vmcnt(N), N > 0) instead of draining the memory pipeline every row.
-  auto load_window = [&](int r, double& w, double& t, double& fr) {
+  // Old values come in three streams per row r, all read at this lane's column jr = J*64 + lane - r of that row:
+  //   W[r] = v[r][jr]   S[r] = v[r][jr + 1]   S2[r] = v[r][jr + 2]     and  F[r] = f[r][jr].
+  // For row i: own = W[i], E = S[i]; the row below: SW = W[i+1], S = S[i+1], SE = S2[i+1] (its columns sit one lane to the
+  // right).  No cross-lane traffic for old values; the overlapping loads are served by the L1.  Rows nr.. are the zero
+  // halo rows.  RAW = the window and the two columns right of it lie inside the grid on that row: no clamping, no masks.
+  struct Old {
+    double w, s, s2, f;
+  };
+  auto load_row = [&](auto raw, int r) __attribute__((always_inline)) {
+    Old o;
+    o.w = 0.0;
+    o.s2 = 0.0;
     const int rr = r < nr ? r : nr;
-    const int jw = J * 64 - r + lane;
-    const int jt = jw + 2;  // lanes 62, 63: columns J*64 + 64 - r and + 65 - r
-    const int jwc = jw < 0 ? 0 : (jw > nc - 1 ? nc - 1 : jw);
-    const int jtc = jt < 0 ? 0 : (jt > nc - 1 ? nc - 1 : jt);
     const double* row = v + (long)rr * nc;
-    const double wv = row[jwc];
-    const double tv = row[jtc];
-    fr = f[(long)rr * nc + jwc];
-    w = (jw >= 0 && jw < nc) ? wv : 0.0;
-    t = (lane >= 62 && jt >= 0 && jt < nc) ? tv : 0.0;
+    const double* frow = f + (long)rr * nc;
+    const int jw = J * 64 - r + lane;
+    if (decltype(raw)::value) {
+      if (OWN || !FIVE) o.w = row[jw];
+      o.s = row[jw + 1];
+      if (!FIVE) o.s2 = row[jw + 2];
+      o.f = frow[jw];
+    } else {
+      auto at = [&](const double* base, int j) __attribute__((always_inline)) {
+        const int jc = j < 0 ? 0 : (j > nc - 1 ? nc - 1 : j);
+        const double x = base[jc];
+        return (j >= 0 && j < nc) ? x : 0.0;
+      };
+      if (OWN || !FIVE) o.w = at(row, jw);
+      o.s = at(row, jw + 1);
+      if (!FIVE) o.s2 = at(row, jw + 2);
+      o.f = at(frow, jw);
+    }
+    return o;
   };
 
-  // edge records of the left block: the four granules of a row are read by lanes 0..3 (every lane loads, the address
-  // is clamped), two rows before they are needed, so their round trip to L2 hides behind those rows
+  // edge records of the left block: the four granules of a row are read by lanes 0..3 (every lane loads, the address is
+  // clamped), kAhead rows before they are needed, so their round trip hides behind those rows
   const u64* rec_src = J > 0 ? left_rec : my_rec;  // (block 0 has no left neighbour: any valid address, result unused)
-  auto load_record = [&](int row) {
+  auto load_record = [&](int row) __attribute__((always_inline)) {
     const int rc = row < 0 ? 0 : (row > nr - 1 ? nr - 1 : row);
     return load_granule(rec_src + (long)rc * 4 + (lane & 3));
   };
   bool failed = false;
-  auto unpack = [&](u64 R, double& c1, double& c2) {  // false: the record is not complete yet
-    const u64 g0 = lane_bits(R, 0), g1 = lane_bits(R, 1), g2 = lane_bits(R, 2), g3 = lane_bits(R, 3);
-    c2 = __builtin_bit_cast(double, (g0 & 0xffffffffull) | (g1 << 32));  // the left block's lane 62
-    c1 = __builtin_bit_cast(double, (g2 & 0xffffffffull) | (g3 << 32));  // ... lane 63
-    return ((g0 & g1 & g2 & g3) >> 32) == 1ull;
+  auto unpack = [&](u64 R, double& c1, double& c2) __attribute__((always_inline)) {  // false: the record is not complete yet
+    const u64 g2 = lane_bits(R, 2), g3 = lane_bits(R, 3);
+    c1 = __builtin_bit_cast(double, (g2 & 0xffffffffull) | (g3 << 32));  // the left block's lane 63
+    u64 tags = g2 & g3;
+    c2 = 0.0;
+    if (!FIVE) {
+      const u64 g0 = lane_bits(R, 0), g1 = lane_bits(R, 1);
+      c2 = __builtin_bit_cast(double, (g0 & 0xffffffffull) | (g1 << 32));  // ... lane 62
+      tags &= g0 & g1;
+    }
+    return (tags >> 32) == 1ull;
   };
-  auto wait_record = [&](int row, double& c1, double& c2) {  // the slow path: ask until the record is complete
+  auto wait_record = [&](int row, double& c1, double& c2) __attribute__((always_inline)) {  // the slow path: ask until the record is complete
     u64 t0 = 0;
     bool timing = false;
     while (true) {
@@ -189,7 +225,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
         timing = true;
       }
       nap();
-      if (now_ticks() - t0 > kTimeoutTicks || load_word(a.sync + 1) != 0u) {
+      if (now_ticks() - t0 > kTimeoutTicks || load_word(err_word) != 0u) {
         failed = true;
         c1 = 0.0;
         c2 = 0.0;
@@ -199,60 +235,52 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   };
 
   // pipeline registers: rows i .. i + kDepth of old values, the records of rows i .. i + kAhead - 1
-  double wn[kDepth + 1], tl[kDepth + 1], fr[kDepth + 1];
+  Old old[kDepth + 1];
 #pragma unroll
-  for (int d = 0; d <= kDepth; ++d) load_window(i0 + d, wn[d], tl[d], fr[d]);
+  for (int d = 0; d <= kDepth; ++d) old[d] = load_row(Checked<false>{}, i0 + d);
   u64 rq[kAhead];
 #pragma unroll
   for (int d = 0; d < kAhead; ++d) rq[d] = load_record(i0 + d);
 
-  double prev = 0.0;           // new values of the previous row (this lane's column + 1 there)
+  double prev = 0.0;            // new values of the previous row (this lane's column + 1 there)
   double c1p = 0.0, c2p = 0.0;  // the left block's edge values on the previous row
   if (J > 0 && i0 - 1 >= 0 && i0 - 1 <= left_last) wait_record(i0 - 1, c1p, c2p);
-  // e(i) = old value right of this lane's column on row i = s(i - 1): carried from row to row
-  double e = from_right(wn[0], lane) + from_left(tl[0], lane);
 
-  for (int i = i0; i <= i1; ++i) {
+  // one row; FAST: every lane is an interior point on this row and the rows being prefetched need no clamping.  PH = the
+  // pipelines' phase, (i - i0) mod (kDepth + 1): the registers of row i are slot PH, those of row i + 1 slot PH + 1, and
+  // the row fetched now takes slot PH over — a ROTATING register file: a value that is still in flight is never moved
+  // (a register copy would make the wave wait for its load)
+  auto row_step = [&](auto fast, auto ph, int i) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast)::value;
+    constexpr int PH = decltype(ph)::value, NEXT = (PH + 1) % (kDepth + 1);
     const int jmin = J * 64 - i;  // lane 0's column
     // new values of row i-1: NE = this lane, N = lane - 1, NW = lane - 2 (the left block's edge beyond lane 0)
     const double n = from_left(prev, lane) + (lane == 0 ? c1p : 0.0);
     const double ne = prev;
-    // old values: own row, and the row below (SW = this lane of its window, S = lane + 1, SE = lane + 2)
-    const double own = wn[0];
-    const double sw = wn[1];
-    const double s1 = from_right(wn[1], lane);
-    const double s = s1 + from_left(tl[1], lane);
-    double nw = 0.0, se = 0.0;
-    if (!FIVE) {
-      nw = from_left(n, lane) + (lane == 0 ? c2p : 0.0);
-      se = from_right(s1, lane) + tl[1];
-    }
-    const double frow = fr[0];
+    double nw = 0.0;
+    if (!FIVE) nw = from_left(n, lane) + (lane == 0 ? c2p : 0.0);
+    const double own = old[PH].w, e = old[PH].s, fv = old[PH].f;
+    const double sw = old[NEXT].w, s = old[NEXT].s, se = old[NEXT].s2;
+    const u64 rq_now = rq[PH];
     // refill the pipelines (no branch around these loads)
-#pragma unroll
-    for (int dd = 0; dd < kDepth; ++dd) {
-      wn[dd] = wn[dd + 1];
-      tl[dd] = tl[dd + 1];
-      fr[dd] = fr[dd + 1];
-    }
-    load_window(i + kDepth + 1, wn[kDepth], tl[kDepth], fr[kDepth]);
-    const u64 rq_new = load_record(i + kAhead);
+    old[PH] = load_row(fast, i + kDepth + 1);
+    rq[PH] = load_record(i + kAhead);
 
     const int j = jmin + lane;
-    const bool valid = j >= 0 && j < nc;
     double p, qmul;  // x = p + qmul * (value left of lane 0)
-    const bool interior = jmin >= 0 && (FIVE ? jmin + 63 <= nc - 1 : (jmin + 63 <= nc - 2 && i < nr - 1));
-    if (interior) {
-      // every lane is an interior point: constant q, scan of the p part only
-      double lower, upper;
-      if (FIVE) {
-        lower = cN_int * n;
-        upper = fma(cE_int, e, cS_int * s);
-      } else {
-        lower = fma(cNW, nw, fma(cN_int, n, cNE * ne));
-        upper = fma(cE_int, e, fma(cSW, sw, fma(cS_int, s, cSE * se)));
+    bool valid = true;
+    if (FAST) {
+      p = kF * fv;
+      if (OWN) p = fma(kO, own, p);
+      p = fma(kE, e, p);
+      p = fma(kS, s, p);
+      p = fma(kN, n, p);
+      if (!FIVE) {
+        p = fma(kSW, sw, p);
+        p = fma(kSE, se, p);
+        p = fma(kNW, nw, p);
+        p = fma(kNE, ne, p);
       }
-      p = (ad_int * own + beta * frow - wU * upper - wL * lower) * inv_int;
       p = fma(q0, row_shr<1>(p, lane), p);
       p = fma(q2, row_shr<2>(p, lane), p);
       p = fma(q4, row_shr<4>(p, lane), p);
@@ -261,15 +289,31 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       p = fma(Q31, bcast31(p, lane), p);
       qmul = qpow;
     } else {
+      valid = j >= 0 && j < nc;
       const bool last_col = !FIVE && j == nc - 1, last_row = !FIVE && i == nr - 1;
       // the centre-column / own-row coefficients change on the last column / row (Galerkin levels)
-      const double cN = last_col ? a.ccol[0] : cN_int, cS = last_col ? a.ccol[2] : cS_int;
-      const double cW = last_row ? a.crow[0] : cW_int, cE = last_row ? a.crow[2] : cE_int;
-      const double d = last_row ? (last_col ? d_cor : d_row) : (last_col ? d_col : d_int);
-      const double invd = last_row ? (last_col ? inv_cor : inv_row) : (last_col ? inv_col : inv_int);
+      // (assignments under `if`, not `?:` between the captured constants: a select of two captured variables keeps the
+      // whole closure in scratch memory)
+      double cN = cN_int, cS = cS_int, cW = cW_int, cE = cE_int, d = d_int, invd = inv_int;
+      if (last_col) {
+        cN = cN_col;
+        cS = cS_col;
+        d = d_col;
+        invd = inv_col;
+      }
+      if (last_row) {
+        cW = cW_row;
+        cE = cE_row;
+        d = d_row;
+        invd = inv_row;
+        if (last_col) {
+          d = d_cor;
+          invd = inv_cor;
+        }
+      }
       const double lower = fma(cNW, nw, fma(cN, n, cNE * ne));
       const double upper = fma(cE, e, fma(cSW, sw, fma(cS, s, cSE * se)));
-      p = (alpha * d * own + beta * frow - wU * upper - wL * lower) * invd;
+      p = (alpha * d * own + beta * fv - wU * upper - wL * lower) * invd;
       double qq = -wL * cW * invd;
       if (!valid) {
         p = 0.0;
@@ -298,10 +342,11 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     // the value left of lane 0 on this row: the left block's lane 63 (its record was requested kAhead rows ago)
     double c1 = 0.0, c2 = 0.0;
     if (J > 0 && i <= left_last) {
-      if (!unpack(rq[0], c1, c2)) wait_record(i, c1, c2);
+      if (!unpack(rq_now, c1, c2)) wait_record(i, c1, c2);
     }
-    const double x = valid ? fma(qmul, c1, p) : 0.0;
-    if (valid) v[(long)i * nc + j] = x;
+    double x = fma(qmul, c1, p);
+    if (!FAST && !valid) x = 0.0;
+    if (FAST || valid) v[(long)i * nc + j] = x;
     if (publish && lane >= 62) {  // {tag, half} granules of lanes 62 / 63: the right block's NW / N / W values
       const u64 bits = __builtin_bit_cast(u64, x);
       u64* rec = my_rec + (long)i * 4 + (lane - 62) * 2;
@@ -311,13 +356,37 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     prev = x;
     c1p = c1;
     c2p = c2;
-    e = s;  // the row below becomes the own row
-#pragma unroll
-    for (int d = 0; d + 1 < kAhead; ++d) rq[d] = rq[d + 1];
-    rq[kAhead - 1] = rq_new;
-    if (failed) break;
+  };
+  auto step_any = [&](auto fast, int phase, int i) __attribute__((always_inline)) {  // the phase as a run-time value (rows outside the unrolled loop)
+    static_assert(kDepth == 3, "four pipeline phases");
+    if (phase == 0) row_step(fast, Int<0>{}, i);
+    else if (phase == 1) row_step(fast, Int<1>{}, i);
+    else if (phase == 2) row_step(fast, Int<2>{}, i);
+    else row_step(fast, Int<3>{}, i);
+  };
+
+  // rows [fast_lo, fast_hi]: interior on the row itself and unclamped on every row prefetched from it
+  int fast_lo = J * 64 + 66 - nc, fast_hi = J * 64 - kDepth - 1;
+  if (fast_lo < i0) fast_lo = i0;
+  const int last_fast_row = FIVE ? nr - 1 : nr - 2;
+  if (fast_hi > last_fast_row) fast_hi = last_fast_row;
+  if (fast_hi > i1) fast_hi = i1;
+  int i = i0;
+  while (i <= i1 && !failed) {
+    if (((i - i0) & 3) == 0 && i >= fast_lo) {
+      for (; i + 3 <= fast_hi && !failed; i += 4) {  // the bulk: four rows per trip, compile-time phases
+        row_step(Checked<true>{}, Int<0>{}, i);
+        row_step(Checked<true>{}, Int<1>{}, i + 1);
+        row_step(Checked<true>{}, Int<2>{}, i + 2);
+        row_step(Checked<true>{}, Int<3>{}, i + 3);
+      }
+    }
+    if (i <= i1 && !failed) {  // rows around the bulk: the general form of the step
+      step_any(Checked<false>{}, (i - i0) & 3, i);
+      ++i;
+    }
   }
-  if (failed && lane == 0) store_word(a.sync + 1, 1u);  // tell the host and release everyone behind this block
+  if (failed && lane == 0) store_word(err_word, 1u);  // tell the host and release everyone behind this block
 }
 
 }  // namespace
@@ -366,8 +435,10 @@ void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.carry_stride = (long)a.nblocks * g.nr * 4;
   (void)hipMemsetAsync(sync, 0, sizeof(unsigned) * 2, s);
   (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * (size_t)k * a.carry_stride, s);
-  if (a.five) hipLaunchKernelGGL(k_lex_wave<true>, dim3((unsigned)(a.nblocks * k)), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL(k_lex_wave<false>, dim3((unsigned)(a.nblocks * k)), dim3(64), 0, s, a);
+  const dim3 grid((unsigned)(a.nblocks * k));
+  if (a.five && alpha == 0.0) hipLaunchKernelGGL((k_lex_wave<true, false>), grid, dim3(64), 0, s, a);
+  else if (a.five) hipLaunchKernelGGL((k_lex_wave<true, true>), grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((k_lex_wave<false, true>), grid, dim3(64), 0, s, a);
 }
 
 }  // namespace mgcmt

@@ -111,7 +111,7 @@ struct ShardComm {
   hipEvent_t ev_boundary = nullptr, ev_done = nullptr;
   bool pending = false;   // an exchange is in flight on comm_stream: the next pass waits for ev_done
   bool overlap = true;    // RCCL transport only
-  bool split = true;      // boundary rows first (both transports)
+  int split = 1;          // boundary rows first (both transports): 1 on strips of >= 2^22 points, 2 always (tests), 0 never
   bool self_ring = false; // one-rank self-test: the rank is its own neighbour above and below in every exchange
   double* d_red = nullptr;
 };
@@ -224,7 +224,10 @@ int strip_pass(mgcmt_plan* p, int l, int kind, int n, double omega, int mode, in
   const bool ring = c->self_ring;
   const bool up = c->rank > 0 || ring, down = c->rank + 1 < c->nranks || ring;
   const long B = kBoundaryRows;
-  const bool split = c->split && (stores_v || sends_f) && (up || down) && L.nr >= 4 * B;
+  // two extra launches cost about 10 us on the stream; the exchange they free from the critical path is worth more than
+  // that only on strips whose interior launch is long enough to hide it (c->split == 2: always, for tests)
+  const bool big = c->split == 2 || (long)L.nr * L.gc >= (1L << 22);
+  const bool split = c->split && big && (stores_v || sends_f) && (up || down) && L.nr >= 4 * B;
   std::vector<Msg> msgs;
   if (!split) {
     MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre));
@@ -342,7 +345,7 @@ int mgcmt_comm_destroy(mgcmt_plan* p) {
 int mgcmt_comm_set_option(mgcmt_plan* p, int option, int value) {
   MG_TRY(check_comm(p));
   if (option == MGCMT_COMM_OPT_OVERLAP) p->comm->overlap = value != 0 && p->comm->nccl != nullptr;
-  else if (option == MGCMT_COMM_OPT_SPLIT) p->comm->split = value != 0;
+  else if (option == MGCMT_COMM_OPT_SPLIT) p->comm->split = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (option == MGCMT_COMM_OPT_SELF_RING) {
     if (value && p->comm->nranks != 1) return fail(MGCMT_ERR_INVALID, "the self-ring test mode needs a one-rank communicator");
     p->comm->self_ring = value != 0;

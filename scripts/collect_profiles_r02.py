@@ -38,31 +38,68 @@ def waves_per_simd(vgprs):
     return max(1, min(8, 512 // max(alloc, 1)))
 
 
+def clusters(values, ratio=0.62):
+    """Group dispatches of one kernel by size: the same instantiation runs on several levels, each about four times smaller
+    than the one above (two to three times shorter).  Returns for every value the index of its cluster (0 = largest)."""
+    order = sorted(set(values), reverse=True)
+    bounds, top = [], None
+    for x in order:
+        if top is None or x < ratio * top:
+            bounds.append(x)
+            top = x
+    def index(x):
+        k = 0
+        for b, bound in enumerate(bounds):
+            if x <= bound * 1.0000001:
+                k = b
+        return k
+    return [index(x) for x in values]
+
+
 table_rows, detail, traffic = [], {}, {}
 for sm in ("wjacobi", "rb"):
     per = {}
     trace = latest("prof_%s_%s/**/*kernel_trace.csv" % (tag, sm))
     if trace:
-        for r in csv.DictReader(open(trace)):
-            k = per.setdefault(r["Kernel_Name"], {"calls": 0, "ns": 0.0, "vgpr": r.get("VGPR_Count") or r.get("Arch_VGPR_Count"), "sgpr": r.get("SGPR_Count"),
-                                                  "lds": r.get("LDS_Block_Size")})
-            k["calls"] += 1
-            k["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        rows = [r for r in csv.DictReader(open(trace))]
+        by_kernel = {}
+        for r in rows:
+            by_kernel.setdefault(r["Kernel_Name"], []).append(r)
+        for kname, rs in by_kernel.items():
+            durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in rs]
+            lev = clusters(durs) if "k_fused" in kname else [0] * len(durs)
+            for r, d, l in zip(rs, durs, lev):
+                k = per.setdefault((kname, l), {"calls": 0, "ns": 0.0, "vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"), "lds": r.get("LDS_Block_Size")})
+                k["calls"] += 1
+                k["ns"] += d
     for counter_dir, counters in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]),
                                   ("SQ", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAIT_ANY",
                                           "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"])):
         f = latest("pmc_%s_%s_%s/**/*counter_collection.csv" % (tag, sm, counter_dir))
         if not f:
             continue
+        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] in counters]
+        # level of a dispatch: from the counter that scales with the level's size (bytes moved / wave cycles)
+        key_counter = counters[0] if counter_dir != "SQ" else "SQ_WAVE_CYCLES"
+        size_of = {}
+        for r in rows:
+            if r["Counter_Name"] == key_counter:
+                size_of.setdefault(r["Kernel_Name"], {})[r["Dispatch_Id"]] = float(r["Counter_Value"])
+        level_of = {}
+        for kname, d in size_of.items():
+            ids, vals = list(d.keys()), list(d.values())
+            lev = clusters(vals) if "k_fused" in kname else [0] * len(vals)
+            for i, l in zip(ids, lev):
+                level_of[(kname, i)] = l
         acc = {}
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] in counters:
-                a = acc.setdefault((r["Kernel_Name"], r["Counter_Name"]), [0.0, 0])
-                a[0] += float(r["Counter_Value"])
-                a[1] += 1
-        for (kname, cname), (tot, cnt) in acc.items():
-            per.setdefault(kname, {"calls": 0, "ns": 0.0, "vgpr": None, "sgpr": None, "lds": None})[cname] = tot / cnt
-    for kname, k in sorted(per.items(), key=lambda kv: -kv[1]["ns"]):
+        for r in rows:
+            l = level_of.get((r["Kernel_Name"], r["Dispatch_Id"]), 0)
+            a = acc.setdefault((r["Kernel_Name"], l, r["Counter_Name"]), [0.0, 0])
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+        for (kname, l, cname), (tot, cnt) in acc.items():
+            per.setdefault((kname, l), {"calls": 0, "ns": 0.0, "vgpr": None, "sgpr": None, "lds": None})[cname] = tot / cnt
+    for (kname, lev), k in sorted(per.items(), key=lambda kv: -kv[1]["ns"]):
         if not k["calls"] or "k_probe" in kname or "rocclr" in kname:
             continue
         avg_us = k["ns"] / k["calls"] / 1e3
@@ -71,13 +108,14 @@ for sm in ("wjacobi", "rb"):
         hbm = (fetch * 2048 + write * 1024) if fetch is not None and write is not None else None
         valu = (100.0 * k["SQ_ACTIVE_INST_VALU"] / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None
         wait = (100.0 * k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None
-        table_rows.append((sm, short(kname), k["calls"], avg_us, k["vgpr"], waves_per_simd(k["vgpr"]) if k["vgpr"] else None, valu, wait,
+        label = short(kname) + (" [size class %d]" % lev if "k_fused" in kname else "")
+        table_rows.append((sm, label, k["calls"], avg_us, k["vgpr"], waves_per_simd(k["vgpr"]) if k["vgpr"] else None, valu, wait,
                            hbm, (hbm / (avg_us * 1e-6) / 1e12) if hbm else None))
         if hbm is not None:
-            detail["%s_%d %s" % (sm, n, short(kname))] = {"avg_us": avg_us, "FETCH_SIZE_KB_avg": fetch, "WRITE_SIZE_KB_avg": write,
-                                                          "fetch_bytes_corrected_x2": fetch * 2048, "write_bytes": write * 1024, "hbm_bytes": hbm}
+            detail["%s_%d %s" % (sm, n, label)] = {"avg_us": avg_us, "FETCH_SIZE_KB_avg": fetch, "WRITE_SIZE_KB_avg": write,
+                                                   "fetch_bytes_corrected_x2": fetch * 2048, "write_bytes": write * 1024, "hbm_bytes": hbm}
         want = "k_fused<Op5, %d, 2, 0>" % (0 if sm == "wjacobi" else 1)
-        if short(kname) == want and hbm is not None:
+        if short(kname) == want and lev == 0 and hbm is not None:
             traffic["%s_%d" % (sm, n)] = hbm
     stats = latest("prof_%s_%s/**/*kernel_stats.csv" % (tag, sm))
     if stats:
@@ -108,7 +146,7 @@ with open(os.path.join(out, "%s_kernel_table.md" % prefix), "w") as fh:
     fh.write("rocprofv3 kernel trace + PMC passes of `bench.py --smoother <sm>` (scripts/gpu_r02_profiles.sh).  waves/SIMD = what the VGPR\n"
              "allocation admits (MI355X_MICROARCH.md, Register files); VALU %% = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, wait %% = SQ_WAIT_ANY /\n"
              "SQ_WAVE_CYCLES (both per wave); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE per launch; TB/s = those bytes / average launch time.\n"
-             "Template arguments of k_fused: <operator policy, smoother (0 Jacobi, 1 red-black, 2 four-colour), sweeps, flags (1 prolong, 2 restrict,\n4 zero-in, 8 no-store, 16/32 recomputed sweeps)>.\n\n")
+             "One instantiation runs on several levels; \"size class\" groups its dispatches by size (0 = the largest level it runs on: Op5 =\n16384^2, Op9c = 8192^2; every class is about four times fewer points; the smallest classes are merged).\nTemplate arguments of k_fused: <operator policy, smoother (0 Jacobi, 1 red-black, 2 four-colour), sweeps, flags (1 prolong, 2 restrict,\n4 zero-in, 8 no-store, 16/32 recomputed sweeps)>.\n\n")
     fh.write("| cycle | kernel | launches | avg us | VGPRs | waves/SIMD | VALU % | wait % | HBM MB/launch | TB/s |\n|---|---|---|---|---|---|---|---|---|---|\n")
     for sm, k, calls, us, vg, wps, valu, wait, hbm, rate in table_rows:
         fh.write("| %s | `%s` | %d | %.1f | %s | %s | %s | %s | %s | %s |\n" % (

@@ -24,6 +24,7 @@ sp = ShardedPlan(op, 8, rank, world, device=0, switch_grid=g // 4)
 assert sp._torch_transport.stage_host
 sp.plan.set_option(_lib.OPT_RECOMPUTE, 2)
 sp.set_shift(0.3)
+sp.set_comm_option(_lib.COMM_OPT_SPLIT, 2)
 rng = np.random.RandomState(9)
 f, v0 = rng.rand(g * g), rng.rand(g * g)
 rows = g // world

@@ -70,6 +70,7 @@ for transport in ("rccl", "torch"):
         # 2. the cycle with the rank as its own neighbour: split launches, RCCL on the second stream, overlap — the rows
         #    received land in halo rows the fused kernels of a whole-grid level never read, so the result is unchanged
         sp.set_comm_option(_lib.COMM_OPT_SELF_RING, 1)
+        sp.set_comm_option(_lib.COMM_OPT_SPLIT, 2)
         for _ in range(2):
             sp.vcycle(2, 2, _lib.GS_MC, omega=1.0, nu_coarse=2)
         ring_result = sp.download_local(_lib.SLOT_V)

@@ -35,6 +35,7 @@ def _worker(rank, world, port, g, kind, omega, nu, out_dir, force_recompute):
     op = laplacian_operator(g, "2d") * (-1 / np.pi ** 2)
     sp = ShardedPlan(op, 8, rank, world, switch_grid=g // 4, on_gpu=False)
     sp.set_shift(0.4)
+    sp.set_comm_option(_lib.COMM_OPT_SPLIT, 2)      # boundary rows first on these small strips too
     if force_recompute:
         sp.plan.set_option(_lib.OPT_RECOMPUTE, 2)   # take the recompute-instead-of-store passes on these small strips too
     rng = np.random.RandomState(5)
