@@ -30,9 +30,8 @@ namespace mgcmt {
 
 namespace {
 
-constexpr int kDepth = 3;   // rows of old values in flight ahead of the row being processed
-constexpr int kAhead = kDepth + 1;   // rows by which the left block's edge records are requested ahead of their use (their stores
-                            // are write-through, so the loads come from memory, not from L2: 1-2 us)
+constexpr int kDepth = 7;   // rows of old values (and edge records) in flight ahead of the row being processed
+constexpr int kSlots = kDepth + 1;
 
 struct LexWaveArgs {
   double* v;
@@ -50,6 +49,27 @@ struct LexWaveArgs {
 };
 
 typedef unsigned long long u64;
+
+// Loads of the row loop are hand-counted: issued as asm (the compiler does not see them, so it neither waits for them nor
+// drains them), consumed behind ONE s_waitcnt vmcnt(N) per row whose N = the memory operations issued since the youngest
+// value that row needs (vector-memory operations complete in order, stores included).  The destinations are read-write
+// operands, so a slot keeps its registers; the wait names every register it releases, so no use moves above it
+// (cdna_hip_programming.md §5.7, form (ii)).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MGCMT_LEX_LOAD(dst, ptr) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory")
+#define MGCMT_LEX_LOAD_SC1(dst, ptr) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(dst) : "v"(ptr) : "memory")
+template <int N>
+__device__ __forceinline__ void wait_loads(double& a, double& b, double& c, double& d, double& e, double& f, double& g, unsigned long long& r) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(r) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void drain_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
+#define MGCMT_LEX_LOAD(dst, ptr) (dst) = *(ptr)
+#define MGCMT_LEX_LOAD_SC1(dst, ptr) (dst) = *(ptr)
+template <int N>
+__device__ __forceinline__ void wait_loads(double&, double&, double&, double&, double&, double&, double&, unsigned long long&) {}
+__device__ __forceinline__ void drain_loads() {}
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int CTRL>
@@ -130,7 +150,6 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   const int i0 = J * 64 - (nc - 1) > 0 ? J * 64 - (nc - 1) : 0;  // first row with a column of this block inside the grid
   const int i1 = J * 64 + 63 < nr - 1 ? J * 64 + 63 : nr - 1;    // last one
   const int left_last = J > 0 ? (J * 64 - 1 < nr - 1 ? J * 64 - 1 : nr - 1) : -1;  // last row the left block works on
-  const bool publish = J + 1 < a.nblocks;
   unsigned* const err_word = a.sync + 1;  // (locals, not `a`, inside the lambdas: the argument block then stays out of memory)
   if (i0 > i1) return;  // (cannot happen for nblocks = ceil((nr + nc - 1) / 64); kept as a guard)
 
@@ -164,39 +183,49 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // For row i: own = W[i], E = S[i]; the row below: SW = W[i+1], S = S[i+1], SE = S2[i+1] (its columns sit one lane to the
   // right).  No cross-lane traffic for old values; the overlapping loads are served by the L1.  Rows nr.. are the zero
   // halo rows.  RAW = the window and the two columns right of it lie inside the grid on that row: no clamping, no masks.
-  struct Old {
-    double w, s, s2, f;
-  };
-  auto load_row = [&](auto raw, int r) __attribute__((always_inline)) {
-    Old o;
-    o.w = 0.0;
-    o.s2 = 0.0;
+  constexpr bool USE_W = OWN || !FIVE, USE_S2 = !FIVE;
+  constexpr int kLoads = 3 + (USE_W ? 1 : 0) + (USE_S2 ? 1 : 0);  // per row: [W] S [S2] F + the edge record
+  constexpr int kOps = kLoads + 2;                                 // ... + the row's store and its record's store
+  constexpr int kWaitN = (kDepth - 1) * kOps;                      // rows i+2 .. i+kDepth may still be in flight
+  static_assert(kWaitN <= 63, "vmcnt is a 6-bit counter");
+  double Wv[kSlots], Sv[kSlots], S2v[kSlots], Fv[kSlots];
+  u64 Rv[kSlots];
+#pragma unroll
+  for (int d = 0; d < kSlots; ++d) {
+    Wv[d] = 0.0;
+    Sv[d] = 0.0;
+    S2v[d] = 0.0;
+    Fv[d] = 0.0;
+    Rv[d] = 0;
+  }
+  const u64* rec_src = J > 0 ? left_rec : my_rec;  // (block 0 has no left neighbour: any valid address, result unused)
+  // issue the loads of row r into slot SL (RAW: no clamping needed on that row); masks are applied when the row is used
+  auto issue_row = [&](auto raw, auto slot, int r) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot)::value;
     const int rr = r < nr ? r : nr;
     const double* row = v + (long)rr * nc;
     const double* frow = f + (long)rr * nc;
     const int jw = J * 64 - r + lane;
-    if (decltype(raw)::value) {
-      if (OWN || !FIVE) o.w = row[jw];
-      o.s = row[jw + 1];
-      if (!FIVE) o.s2 = row[jw + 2];
-      o.f = frow[jw];
-    } else {
-      auto at = [&](const double* base, int j) __attribute__((always_inline)) {
-        const int jc = j < 0 ? 0 : (j > nc - 1 ? nc - 1 : j);
-        const double x = base[jc];
-        return (j >= 0 && j < nc) ? x : 0.0;
-      };
-      if (OWN || !FIVE) o.w = at(row, jw);
-      o.s = at(row, jw + 1);
-      if (!FIVE) o.s2 = at(row, jw + 2);
-      o.f = at(frow, jw);
+    int j0 = jw, j1 = jw + 1, j2 = jw + 2;
+    if (!decltype(raw)::value) {
+      j0 = j0 < 0 ? 0 : (j0 > nc - 1 ? nc - 1 : j0);
+      j1 = j1 < 0 ? 0 : (j1 > nc - 1 ? nc - 1 : j1);
+      j2 = j2 < 0 ? 0 : (j2 > nc - 1 ? nc - 1 : j2);
     }
-    return o;
+    double &w_ = Wv[SL], &s_ = Sv[SL], &s2_ = S2v[SL], &f_ = Fv[SL];  // (named here: a variable that only an asm
+    u64& r_ = Rv[SL];                                                   //  statement mentions is not captured)
+    const double *pw = row + j0, *ps = row + j1, *ps2 = row + j2, *pf = frow + j0;
+    const int rc = r > nr - 1 ? nr - 1 : r;
+    const u64* pr = rec_src + (long)rc * 4 + (lane & 3);
+    if (USE_W) MGCMT_LEX_LOAD(w_, pw);
+    MGCMT_LEX_LOAD(s_, ps);
+    if (USE_S2) MGCMT_LEX_LOAD(s2_, ps2);
+    MGCMT_LEX_LOAD(f_, pf);
+    MGCMT_LEX_LOAD_SC1(r_, pr);
   };
 
   // edge records of the left block: the four granules of a row are read by lanes 0..3 (every lane loads, the address is
-  // clamped), kAhead rows before they are needed, so their round trip hides behind those rows
-  const u64* rec_src = J > 0 ? left_rec : my_rec;  // (block 0 has no left neighbour: any valid address, result unused)
+  // clamped), kDepth + 1 rows before they are needed, with the row's old values; the slow path asks again, visibly
   auto load_record = [&](int row) __attribute__((always_inline)) {
     const int rc = row < 0 ? 0 : (row > nr - 1 ? nr - 1 : row);
     return load_granule(rec_src + (long)rc * 4 + (lane & 3));
@@ -234,13 +263,19 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     }
   };
 
-  // pipeline registers: rows i .. i + kDepth of old values, the records of rows i .. i + kAhead - 1
-  Old old[kDepth + 1];
+  // fill the pipeline: rows i0 .. i0 + kDepth (the one place where everything in flight is waited for)
+  issue_row(Checked<false>{}, Int<0>{}, i0);
+  issue_row(Checked<false>{}, Int<1>{}, i0 + 1);
+  issue_row(Checked<false>{}, Int<2>{}, i0 + 2);
+  issue_row(Checked<false>{}, Int<3>{}, i0 + 3);
+  issue_row(Checked<false>{}, Int<4>{}, i0 + 4);
+  issue_row(Checked<false>{}, Int<5>{}, i0 + 5);
+  issue_row(Checked<false>{}, Int<6>{}, i0 + 6);
+  issue_row(Checked<false>{}, Int<7>{}, i0 + 7);
+  static_assert(kSlots == 8, "eight pipeline slots");
+  drain_loads();
 #pragma unroll
-  for (int d = 0; d <= kDepth; ++d) old[d] = load_row(Checked<false>{}, i0 + d);
-  u64 rq[kAhead];
-#pragma unroll
-  for (int d = 0; d < kAhead; ++d) rq[d] = load_record(i0 + d);
+  for (int d = 0; d < kSlots; ++d) wait_loads<0>(Wv[d], Sv[d], S2v[d], Fv[d], Wv[d], Sv[d], S2v[d], Rv[d]);
 
   double prev = 0.0;            // new values of the previous row (this lane's column + 1 there)
   double c1p = 0.0, c2p = 0.0;  // the left block's edge values on the previous row
@@ -252,19 +287,26 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // (a register copy would make the wave wait for its load)
   auto row_step = [&](auto fast, auto ph, int i) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast)::value;
-    constexpr int PH = decltype(ph)::value, NEXT = (PH + 1) % (kDepth + 1);
+    constexpr int PH = decltype(ph)::value, NEXT = (PH + 1) % kSlots;
     const int jmin = J * 64 - i;  // lane 0's column
+    // rows i and i + 1 have landed when at most the loads and stores of the kDepth - 1 rows behind them are in flight
+    wait_loads<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH]);
+    double own = Wv[PH], e = Sv[PH], fv = Fv[PH];
+    double sw = Wv[NEXT], s = Sv[NEXT], se = S2v[NEXT];
+    const u64 rq_now = Rv[PH];
+    if (!FAST) {  // columns outside the grid read as zero (the addresses were clamped)
+      const int j = jmin + lane;
+      if (!(j >= 0 && j < nc)) own = 0.0, fv = 0.0;
+      if (!(j + 1 >= 0 && j + 1 < nc)) e = 0.0;
+      if (!(j - 1 >= 0 && j - 1 < nc)) sw = 0.0;
+      if (!(j >= 0 && j < nc)) s = 0.0;
+      if (!(j + 1 >= 0 && j + 1 < nc)) se = 0.0;
+    }
     // new values of row i-1: NE = this lane, N = lane - 1, NW = lane - 2 (the left block's edge beyond lane 0)
     const double n = from_left(prev, lane) + (lane == 0 ? c1p : 0.0);
     const double ne = prev;
     double nw = 0.0;
     if (!FIVE) nw = from_left(n, lane) + (lane == 0 ? c2p : 0.0);
-    const double own = old[PH].w, e = old[PH].s, fv = old[PH].f;
-    const double sw = old[NEXT].w, s = old[NEXT].s, se = old[NEXT].s2;
-    const u64 rq_now = rq[PH];
-    // refill the pipelines (no branch around these loads)
-    old[PH] = load_row(fast, i + kDepth + 1);
-    rq[PH] = load_record(i + kAhead);
 
     const int j = jmin + lane;
     double p, qmul;  // x = p + qmul * (value left of lane 0)
@@ -339,7 +381,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
 #undef MGCMT_LEX_STEP
       qmul = qq;
     }
-    // the value left of lane 0 on this row: the left block's lane 63 (its record was requested kAhead rows ago)
+    // the value left of lane 0 on this row: the left block's lane 63 (its record came with the row's old values)
     double c1 = 0.0, c2 = 0.0;
     if (J > 0 && i <= left_last) {
       if (!unpack(rq_now, c1, c2)) wait_record(i, c1, c2);
@@ -347,22 +389,34 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     double x = fma(qmul, c1, p);
     if (!FAST && !valid) x = 0.0;
     if (FAST || valid) v[(long)i * nc + j] = x;
-    if (publish && lane >= 62) {  // {tag, half} granules of lanes 62 / 63: the right block's NW / N / W values
-      const u64 bits = __builtin_bit_cast(u64, x);
-      u64* rec = my_rec + (long)i * 4 + (lane - 62) * 2;
-      store_granule(rec, (1ull << 32) | (bits & 0xffffffffull));
-      store_granule(rec + 1, (1ull << 32) | (bits >> 32));
+    {  // the row's edge record: {tag, half a double} granules, ONE store instruction (lanes 60..63; FIVE: 62, 63)
+      const double t1 = from_right(x, lane);   // lane 62: x63, lane 61: x62
+      const double t2 = from_right(t1, lane);  // lane 60: x62
+      const double src = lane == 63 ? x : (lane == 60 ? t2 : t1);
+      const u64 bits = __builtin_bit_cast(u64, src);
+      const u64 word = (1ull << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xffffffffull));
+      if (lane >= (FIVE ? 62 : 60)) store_granule(my_rec + (long)i * 4 + (lane - 60), word);
     }
     prev = x;
     c1p = c1;
     c2p = c2;
+    // refill: row i + kDepth + 1 takes this slot over.  LAST in the step: the slot's old values are dead by now, so the
+    // loads land in the very registers the slot had (issued earlier, the old and the new value would be alive together, the
+    // slots would rotate through registers, and the copies that restore them at the loop's latch would read registers whose
+    // loads are still in flight)
+    issue_row(fast, ph, i + kDepth + 1);
   };
   auto step_any = [&](auto fast, int phase, int i) __attribute__((always_inline)) {  // the phase as a run-time value (rows outside the unrolled loop)
-    static_assert(kDepth == 3, "four pipeline phases");
-    if (phase == 0) row_step(fast, Int<0>{}, i);
-    else if (phase == 1) row_step(fast, Int<1>{}, i);
-    else if (phase == 2) row_step(fast, Int<2>{}, i);
-    else row_step(fast, Int<3>{}, i);
+    switch (phase) {
+      case 0: row_step(fast, Int<0>{}, i); break;
+      case 1: row_step(fast, Int<1>{}, i); break;
+      case 2: row_step(fast, Int<2>{}, i); break;
+      case 3: row_step(fast, Int<3>{}, i); break;
+      case 4: row_step(fast, Int<4>{}, i); break;
+      case 5: row_step(fast, Int<5>{}, i); break;
+      case 6: row_step(fast, Int<6>{}, i); break;
+      default: row_step(fast, Int<7>{}, i); break;
+    }
   };
 
   // rows [fast_lo, fast_hi]: interior on the row itself and unclamped on every row prefetched from it
@@ -373,16 +427,20 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   if (fast_hi > i1) fast_hi = i1;
   int i = i0;
   while (i <= i1 && !failed) {
-    if (((i - i0) & 3) == 0 && i >= fast_lo) {
-      for (; i + 3 <= fast_hi && !failed; i += 4) {  // the bulk: four rows per trip, compile-time phases
+    if (((i - i0) & 7) == 0 && i >= fast_lo) {
+      for (; i + 7 <= fast_hi && !failed; i += 8) {  // the bulk: eight rows per trip, compile-time phases
         row_step(Checked<true>{}, Int<0>{}, i);
         row_step(Checked<true>{}, Int<1>{}, i + 1);
         row_step(Checked<true>{}, Int<2>{}, i + 2);
         row_step(Checked<true>{}, Int<3>{}, i + 3);
+        row_step(Checked<true>{}, Int<4>{}, i + 4);
+        row_step(Checked<true>{}, Int<5>{}, i + 5);
+        row_step(Checked<true>{}, Int<6>{}, i + 6);
+        row_step(Checked<true>{}, Int<7>{}, i + 7);
       }
     }
     if (i <= i1 && !failed) {  // rows around the bulk: the general form of the step
-      step_any(Checked<false>{}, (i - i0) & 3, i);
+      step_any(Checked<false>{}, (i - i0) & 7, i);
       ++i;
     }
   }
