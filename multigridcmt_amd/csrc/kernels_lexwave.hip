@@ -30,8 +30,9 @@ namespace mgcmt {
 
 namespace {
 
-constexpr int kDepth = 7;   // rows of old values (and edge records) in flight ahead of the row being processed
-constexpr int kSlots = kDepth + 1;
+// Rows of old values (and edge records) in flight ahead of the row being processed: vector-memory operations complete in
+// order and a row's write-through record store takes microseconds to be acknowledged, so the depth that hides it is as
+// many rows as the 6-bit vmcnt counter can hold operations for (5 to 7 per row)
 
 struct LexWaveArgs {
   double* v;
@@ -127,6 +128,13 @@ template <int N>
 struct Int {
   static constexpr int value = N;
 };
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void for_slots(F&& f) {
+  if constexpr (I < N) {
+    f(Int<I>{});
+    for_slots<N, I + 1>(f);
+  }
+}
 
 constexpr u64 kTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz counter: a stuck pipeline gives up
 
@@ -186,6 +194,8 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   constexpr bool USE_W = OWN || !FIVE, USE_S2 = !FIVE;
   constexpr int kLoads = 3 + (USE_W ? 1 : 0) + (USE_S2 ? 1 : 0);  // per row: [W] S [S2] F + the edge record
   constexpr int kOps = kLoads + 2;                                 // ... + the row's store and its record's store
+  constexpr int kSlots = kOps <= 5 ? 12 : (kOps == 6 ? 10 : 9);    // pipeline slots = rows in flight + the one in use
+  constexpr int kDepth = kSlots - 1;
   constexpr int kWaitN = (kDepth - 1) * kOps;                      // rows i+2 .. i+kDepth may still be in flight
   static_assert(kWaitN <= 63, "vmcnt is a 6-bit counter");
   double Wv[kSlots], Sv[kSlots], S2v[kSlots], Fv[kSlots];
@@ -199,24 +209,32 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     Rv[d] = 0;
   }
   const u64* rec_src = J > 0 ? left_rec : my_rec;  // (block 0 has no left neighbour: any valid address, result unused)
-  // issue the loads of row r into slot SL (RAW: no clamping needed on that row); masks are applied when the row is used
-  auto issue_row = [&](auto raw, auto slot, int r) __attribute__((always_inline)) {
+  // issue the loads of row r into slot SL: addresses clamped into the row, masks applied when the row is used.
+  // PLAIN: compiler-visible loads (the prologue, which the compiler may schedule and wait for as it likes); otherwise the
+  // hand-counted asm loads of the row loop
+  auto issue_row = [&](auto plain, auto slot, int r) __attribute__((always_inline)) {
     constexpr int SL = decltype(slot)::value;
     const int rr = r < nr ? r : nr;
     const double* row = v + (long)rr * nc;
     const double* frow = f + (long)rr * nc;
     const int jw = J * 64 - r + lane;
     int j0 = jw, j1 = jw + 1, j2 = jw + 2;
-    if (!decltype(raw)::value) {
-      j0 = j0 < 0 ? 0 : (j0 > nc - 1 ? nc - 1 : j0);
-      j1 = j1 < 0 ? 0 : (j1 > nc - 1 ? nc - 1 : j1);
-      j2 = j2 < 0 ? 0 : (j2 > nc - 1 ? nc - 1 : j2);
-    }
+    j0 = j0 < 0 ? 0 : (j0 > nc - 1 ? nc - 1 : j0);
+    j1 = j1 < 0 ? 0 : (j1 > nc - 1 ? nc - 1 : j1);
+    j2 = j2 < 0 ? 0 : (j2 > nc - 1 ? nc - 1 : j2);
     double &w_ = Wv[SL], &s_ = Sv[SL], &s2_ = S2v[SL], &f_ = Fv[SL];  // (named here: a variable that only an asm
     u64& r_ = Rv[SL];                                                   //  statement mentions is not captured)
     const double *pw = row + j0, *ps = row + j1, *ps2 = row + j2, *pf = frow + j0;
     const int rc = r > nr - 1 ? nr - 1 : r;
     const u64* pr = rec_src + (long)rc * 4 + (lane & 3);
+    if (decltype(plain)::value) {
+      if (USE_W) w_ = *pw;
+      s_ = *ps;
+      if (USE_S2) s2_ = *ps2;
+      f_ = *pf;
+      r_ = load_granule(pr);
+      return;
+    }
     if (USE_W) MGCMT_LEX_LOAD(w_, pw);
     MGCMT_LEX_LOAD(s_, ps);
     if (USE_S2) MGCMT_LEX_LOAD(s2_, ps2);
@@ -263,19 +281,10 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     }
   };
 
-  // fill the pipeline: rows i0 .. i0 + kDepth (the one place where everything in flight is waited for)
-  issue_row(Checked<false>{}, Int<0>{}, i0);
-  issue_row(Checked<false>{}, Int<1>{}, i0 + 1);
-  issue_row(Checked<false>{}, Int<2>{}, i0 + 2);
-  issue_row(Checked<false>{}, Int<3>{}, i0 + 3);
-  issue_row(Checked<false>{}, Int<4>{}, i0 + 4);
-  issue_row(Checked<false>{}, Int<5>{}, i0 + 5);
-  issue_row(Checked<false>{}, Int<6>{}, i0 + 6);
-  issue_row(Checked<false>{}, Int<7>{}, i0 + 7);
-  static_assert(kSlots == 8, "eight pipeline slots");
+  // fill the pipeline: rows i0 .. i0 + kDepth, with loads the compiler sees (it waits for them before the row loop's
+  // first asm statement reads their registers; from then on nothing but the loop's own asm touches a slot)
+  for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) { issue_row(Checked<true>{}, sl, i0 + decltype(sl)::value); });
   drain_loads();
-#pragma unroll
-  for (int d = 0; d < kSlots; ++d) wait_loads<0>(Wv[d], Sv[d], S2v[d], Fv[d], Wv[d], Sv[d], S2v[d], Rv[d]);
 
   double prev = 0.0;            // new values of the previous row (this lane's column + 1 there)
   double c1p = 0.0, c2p = 0.0;  // the left block's edge values on the previous row
@@ -285,10 +294,11 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // pipelines' phase, (i - i0) mod (kDepth + 1): the registers of row i are slot PH, those of row i + 1 slot PH + 1, and
   // the row fetched now takes slot PH over — a ROTATING register file: a value that is still in flight is never moved
   // (a register copy would make the wave wait for its load)
-  auto row_step = [&](auto fast, auto ph, int i) __attribute__((always_inline)) {
-    constexpr bool FAST = decltype(fast)::value;
+  auto row_step = [&](auto ph, int i) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph)::value, NEXT = (PH + 1) % kSlots;
     const int jmin = J * 64 - i;  // lane 0's column
+    // every lane an interior point of this row (and of the stencil's reach): constant q, no masks (wave-uniform)
+    const bool FAST = jmin >= 1 && (FIVE ? jmin + 64 <= nc - 1 : (jmin + 65 <= nc - 2 && i < nr - 1));
     // rows i and i + 1 have landed when at most the loads and stores of the kDepth - 1 rows behind them are in flight
     wait_loads<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH]);
     double own = Wv[PH], e = Sv[PH], fv = Fv[PH];
@@ -404,46 +414,14 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     // loads land in the very registers the slot had (issued earlier, the old and the new value would be alive together, the
     // slots would rotate through registers, and the copies that restore them at the loop's latch would read registers whose
     // loads are still in flight)
-    issue_row(fast, ph, i + kDepth + 1);
+    issue_row(Checked<false>{}, ph, i + kDepth + 1);
   };
-  auto step_any = [&](auto fast, int phase, int i) __attribute__((always_inline)) {  // the phase as a run-time value (rows outside the unrolled loop)
-    switch (phase) {
-      case 0: row_step(fast, Int<0>{}, i); break;
-      case 1: row_step(fast, Int<1>{}, i); break;
-      case 2: row_step(fast, Int<2>{}, i); break;
-      case 3: row_step(fast, Int<3>{}, i); break;
-      case 4: row_step(fast, Int<4>{}, i); break;
-      case 5: row_step(fast, Int<5>{}, i); break;
-      case 6: row_step(fast, Int<6>{}, i); break;
-      default: row_step(fast, Int<7>{}, i); break;
-    }
-  };
-
-  // rows [fast_lo, fast_hi]: interior on the row itself and unclamped on every row prefetched from it
-  int fast_lo = J * 64 + 66 - nc, fast_hi = J * 64 - kDepth - 1;
-  if (fast_lo < i0) fast_lo = i0;
-  const int last_fast_row = FIVE ? nr - 1 : nr - 2;
-  if (fast_hi > last_fast_row) fast_hi = last_fast_row;
-  if (fast_hi > i1) fast_hi = i1;
-  int i = i0;
-  while (i <= i1 && !failed) {
-    if (((i - i0) & 7) == 0 && i >= fast_lo) {
-      for (; i + 7 <= fast_hi && !failed; i += 8) {  // the bulk: eight rows per trip, compile-time phases
-        row_step(Checked<true>{}, Int<0>{}, i);
-        row_step(Checked<true>{}, Int<1>{}, i + 1);
-        row_step(Checked<true>{}, Int<2>{}, i + 2);
-        row_step(Checked<true>{}, Int<3>{}, i + 3);
-        row_step(Checked<true>{}, Int<4>{}, i + 4);
-        row_step(Checked<true>{}, Int<5>{}, i + 5);
-        row_step(Checked<true>{}, Int<6>{}, i + 6);
-        row_step(Checked<true>{}, Int<7>{}, i + 7);
-      }
-    }
-    if (i <= i1 && !failed) {  // rows around the bulk: the general form of the step
-      step_any(Checked<false>{}, (i - i0) & 7, i);
-      ++i;
-    }
-  }
+  // ONE loop over the block's rows, kSlots rows per trip with compile-time phases; the last trip skips the rows behind i1
+  // (a skipped step issues nothing, and nothing behind it consumes)
+  for (int i = i0; i <= i1 && !failed; i += kSlots)
+    for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) {
+      if (i + decltype(sl)::value <= i1) row_step(sl, i + decltype(sl)::value);
+    });
   if (failed && lane == 0) store_word(err_word, 1u);  // tell the host and release everyone behind this block
 }
 
