@@ -263,6 +263,11 @@ int mgcmt_plan_set_option(mgcmt_plan* plan, int option, int value);
 int mgcmt_time_smoother(mgcmt_plan* plan, int level, int kind, int nu, double omega, int reps, double* ms_out,
                         void* stream);
 
+/* diagnostics of the last lexicographic wave-pipeline sweep (kernels_lexwave.hip): out[0] = blocks started, out[1] = error
+ * word (a block timed out), and — only in a build with -DMGCMT_LEXWAVE_DEBUG — per block four words {ticks of the 100 MHz
+ * clock spent in the block, rows, slow-path entries, start tick}. */
+int mgcmt_lex_wave_stats(mgcmt_plan* plan, uint32_t* out, int64_t capacity);
+
 /* empirical HBM ceilings for bench.py: streams the plan's level-`level` vectors (slots V, F -> T) with a
  * plain grid-stride kernel; kind 0 copy (16 B/point), 1 triad (24 B/point), 2 read-only (8 B/point); kinds 3/4/5 use
  * the fused kernels' access pattern instead (128-column windows marching down `blocks` rows): read 1 stream (8 B),

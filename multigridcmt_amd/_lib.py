@@ -115,6 +115,7 @@ _SIGNATURES = {
     "mgcmt_csr_vcycle": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_void_p]),
     "mgcmt_plan_set_option": (c_int, [c_void_p, c_int, c_int]),
     "mgcmt_bandwidth_probe": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _dp, c_void_p]),
+    "mgcmt_lex_wave_stats": (c_int, [c_void_p, POINTER(ctypes.c_uint32), c_int64]),
     "mgcmt_time_smoother": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, _dp, c_void_p]),
 }
 

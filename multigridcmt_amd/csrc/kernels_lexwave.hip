@@ -173,6 +173,10 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // p part of the maps is scanned; the products of q the scan needs are per-lane constants
   const double kF = beta * inv_int, kO = alpha, kE = -wU * cE_int * inv_int, kS = -wU * cS_int * inv_int, kN = -wL * cN_int * inv_int;
   const double kSW = -wU * cSW * inv_int, kSE = -wU * cSE * inv_int, kNW = -wL * cNW * inv_int, kNE = -wL * cNE * inv_int;
+  // ... and for the lane on a 9-point level's last column (its centre-column coefficients and diagonal differ)
+  const double kFc = beta * inv_col, kOc = alpha * d_col * inv_col, kEc = -wU * cE_int * inv_col, kSc = -wU * cS_col * inv_col,
+               kNc = -wL * cN_col * inv_col, kSWc = -wU * cSW * inv_col, kSEc = -wU * cSE * inv_col, kNWc = -wL * cNW * inv_col,
+               kNEc = -wL * cNE * inv_col;
   const double q0 = -wL * cW_int * inv_int;
   const double q2 = q0 * q0, q4 = q2 * q2, q8 = q4 * q4;
   double qpow = q0, Q15 = 0.0, Q31 = 0.0;  // q0^(lane + 1); q0^((lane & 15) + 1) on the second 16 of every 32; q0^(lane - 31) on the upper 32
@@ -183,6 +187,19 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       if ((lane & 16) && m == (lane & 15) + 1) Q15 = acc;
       if (lane >= 32 && m == lane - 31) Q31 = acc;
       if (m == lane + 1) qpow = acc;
+    }
+  }
+  // the last column's multipliers: its own q times one power of q0 less
+  const double qcol = -wL * cW_int * inv_col;
+  const double qc1 = qcol, qc2 = qcol * q0, qc4 = qcol * q0 * q2, qc8 = qcol * q0 * q2 * q4;
+  double qpowc = qcol, Q15c = 0.0, Q31c = 0.0;
+  {
+    double acc = qcol;  // qcol * q0^(m - 1)
+    for (int m = 1; m <= 64; ++m) {
+      if ((lane & 16) && m == (lane & 15) + 1) Q15c = acc;
+      if (lane >= 32 && m == lane - 31) Q31c = acc;
+      if (m == lane + 1) qpowc = acc;
+      acc *= q0;
     }
   }
 
@@ -249,6 +266,10 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     return load_granule(rec_src + (long)rc * 4 + (lane & 3));
   };
   bool failed = false;
+#ifdef MGCMT_LEXWAVE_DEBUG
+  unsigned dbg_slow = 0;
+  const u64 dbg_t0 = now_ticks();
+#endif
   auto unpack = [&](u64 R, double& c1, double& c2) __attribute__((always_inline)) {  // false: the record is not complete yet
     const u64 g2 = lane_bits(R, 2), g3 = lane_bits(R, 3);
     c1 = __builtin_bit_cast(double, (g2 & 0xffffffffull) | (g3 << 32));  // the left block's lane 63
@@ -262,6 +283,9 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     return (tags >> 32) == 1ull;
   };
   auto wait_record = [&](int row, double& c1, double& c2) __attribute__((always_inline)) {  // the slow path: ask until the record is complete
+#ifdef MGCMT_LEXWAVE_DEBUG
+    ++dbg_slow;
+#endif
     u64 t0 = 0;
     bool timing = false;
     while (true) {
@@ -297,20 +321,31 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   auto row_step = [&](auto ph, int i) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph)::value, NEXT = (PH + 1) % kSlots;
     const int jmin = J * 64 - i;  // lane 0's column
-    // every lane an interior point of this row (and of the stencil's reach): constant q, no masks (wave-uniform)
-    const bool FAST = jmin >= 1 && (FIVE ? jmin + 64 <= nc - 1 : (jmin + 65 <= nc - 2 && i < nr - 1));
+    // Three forms of the row, chosen by wave-uniform tests:
+    //   interior   every lane and everything its stencil reaches lies inside the grid: no masks at all;
+    //   edge       the window crosses the grid's left or right edge (or, 9-point, holds its last column): the old values
+    //              outside the grid are masked to zero, lanes outside produce p = 0 and x = 0 — which is all the left edge
+    //              needs: a lane outside contributes nothing to the lanes right of it whatever the scan multiplies it with,
+    //              and the left block's edge value there is an outside lane's 0; the last column (9-point Galerkin levels:
+    //              its own diagonal, N and S coefficients) takes its own constants and its own scan multipliers;
+    //   general    the last row of a 9-point level (own-row coefficients differ): the scan over (p, q) pairs.
+    // The edge rows are the sweep's critical path — row i becomes available to every block only after the block that
+    // holds column 0 on it has finished it — so they must not be slower than the interior rows.
+    const bool INTERIOR = jmin >= 1 && jmin + 64 <= nc - (FIVE ? 1 : 2);
+    const bool FAST = FIVE || i < nr - 1;  // (every row but a 9-point level's last one)
     // rows i and i + 1 have landed when at most the loads and stores of the kDepth - 1 rows behind them are in flight
     wait_loads<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH]);
     double own = Wv[PH], e = Sv[PH], fv = Fv[PH];
     double sw = Wv[NEXT], s = Sv[NEXT], se = S2v[NEXT];
     const u64 rq_now = Rv[PH];
-    if (!FAST) {  // columns outside the grid read as zero (the addresses were clamped)
-      const int j = jmin + lane;
-      if (!(j >= 0 && j < nc)) own = 0.0, fv = 0.0;
-      if (!(j + 1 >= 0 && j + 1 < nc)) e = 0.0;
-      if (!(j - 1 >= 0 && j - 1 < nc)) sw = 0.0;
-      if (!(j >= 0 && j < nc)) s = 0.0;
-      if (!(j + 1 >= 0 && j + 1 < nc)) se = 0.0;
+    const int j = jmin + lane;
+    bool valid = true;
+    if (!INTERIOR) {  // columns outside the grid read as zero (the addresses were clamped)
+      valid = j >= 0 && j < nc;
+      const bool right = j + 1 >= 0 && j + 1 < nc, left = j - 1 >= 0 && j - 1 < nc;
+      if (!valid) own = 0.0, fv = 0.0, s = 0.0;
+      if (!right) e = 0.0, se = 0.0;
+      if (!left) sw = 0.0;
     }
     // new values of row i-1: NE = this lane, N = lane - 1, NW = lane - 2 (the left block's edge beyond lane 0)
     const double n = from_left(prev, lane) + (lane == 0 ? c1p : 0.0);
@@ -318,9 +353,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     double nw = 0.0;
     if (!FIVE) nw = from_left(n, lane) + (lane == 0 ? c2p : 0.0);
 
-    const int j = jmin + lane;
     double p, qmul;  // x = p + qmul * (value left of lane 0)
-    bool valid = true;
     if (FAST) {
       p = kF * fv;
       if (OWN) p = fma(kO, own, p);
@@ -333,15 +366,50 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
         p = fma(kNW, nw, p);
         p = fma(kNE, ne, p);
       }
-      p = fma(q0, row_shr<1>(p, lane), p);
-      p = fma(q2, row_shr<2>(p, lane), p);
-      p = fma(q4, row_shr<4>(p, lane), p);
-      p = fma(q8, row_shr<8>(p, lane), p);
-      p = fma(Q15, bcast15(p, lane), p);
-      p = fma(Q31, bcast31(p, lane), p);
-      qmul = qpow;
+      const bool has_last_col = !FIVE && jmin <= nc - 1 && jmin + 63 >= nc - 1;  // (wave-uniform)
+      if (has_last_col) {
+        // the lane on the last column: its own diagonal and N / S coefficients, and q = -wL cW / d_col in its multipliers
+        const bool lc = j == nc - 1;
+        double pc = kFc * fv;
+        pc = fma(kOc, own, pc);
+        pc = fma(kEc, e, pc);
+        pc = fma(kSc, s, pc);
+        pc = fma(kNc, n, pc);
+        pc = fma(kSWc, sw, pc);
+        pc = fma(kSEc, se, pc);
+        pc = fma(kNWc, nw, pc);
+        pc = fma(kNEc, ne, pc);
+        // (assignments under `if`, not `?:` between captured constants: see the note in the general form below)
+        double m1 = q0, m2 = q2, m4 = q4, m8 = q8, m15 = Q15, m31 = Q31;
+        qmul = qpow;
+        if (lc) {
+          p = pc;
+          m1 = qc1;
+          m2 = qc2;
+          m4 = qc4;
+          m8 = qc8;
+          m15 = Q15c;
+          m31 = Q31c;
+          qmul = qpowc;
+        }
+        if (!valid) p = 0.0;
+        p = fma(m1, row_shr<1>(p, lane), p);
+        p = fma(m2, row_shr<2>(p, lane), p);
+        p = fma(m4, row_shr<4>(p, lane), p);
+        p = fma(m8, row_shr<8>(p, lane), p);
+        p = fma(m15, bcast15(p, lane), p);
+        p = fma(m31, bcast31(p, lane), p);
+      } else {
+        if (!INTERIOR && !valid) p = 0.0;
+        p = fma(q0, row_shr<1>(p, lane), p);
+        p = fma(q2, row_shr<2>(p, lane), p);
+        p = fma(q4, row_shr<4>(p, lane), p);
+        p = fma(q8, row_shr<8>(p, lane), p);
+        p = fma(Q15, bcast15(p, lane), p);
+        p = fma(Q31, bcast31(p, lane), p);
+        qmul = qpow;
+      }
     } else {
-      valid = j >= 0 && j < nc;
       const bool last_col = !FIVE && j == nc - 1, last_row = !FIVE && i == nr - 1;
       // the centre-column / own-row coefficients change on the last column / row (Galerkin levels)
       // (assignments under `if`, not `?:` between the captured constants: a select of two captured variables keeps the
@@ -397,8 +465,8 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       if (!unpack(rq_now, c1, c2)) wait_record(i, c1, c2);
     }
     double x = fma(qmul, c1, p);
-    if (!FAST && !valid) x = 0.0;
-    if (FAST || valid) v[(long)i * nc + j] = x;
+    if (!valid) x = 0.0;
+    if (valid) v[(long)i * nc + j] = x;
     {  // the row's edge record: {tag, half a double} granules, ONE store instruction (lanes 60..63; FIVE: 62, 63)
       const double t1 = from_right(x, lane);   // lane 62: x63, lane 61: x62
       const double t2 = from_right(t1, lane);  // lane 60: x62
@@ -422,6 +490,16 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) {
       if (i + decltype(sl)::value <= i1) row_step(sl, i + decltype(sl)::value);
     });
+#ifdef MGCMT_LEXWAVE_DEBUG
+  if (lane == 0) {  // diagnostic build: per block {ticks (100 MHz), rows, slow-path entries} behind the two sync words
+    unsigned* d = a.sync + 2 + 4 * (q * a.nblocks + J);
+    const u64 dt = now_ticks() - dbg_t0;
+    d[0] = (unsigned)dt;
+    d[1] = (unsigned)(i1 - i0 + 1);
+    d[2] = dbg_slow;
+    d[3] = (unsigned)(dbg_t0 & 0xffffffffu);
+  }
+#endif
   if (failed && lane == 0) store_word(err_word, 1u);  // tell the host and release everyone behind this block
 }
 

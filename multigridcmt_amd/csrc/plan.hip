@@ -281,7 +281,7 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
   const KOp& op = p->levels[l].dA.k;
   if (p->use_lex_wave && p->levels[l].nr == p->levels[l].gr && lex_wave_supported(g, op)) {
     const size_t blocks = (size_t)lex_wave_blocks(g);
-    const size_t need_carry = (size_t)p->nvec * blocks * g.nr * 4, need_sync = 2;
+    const size_t need_carry = (size_t)p->nvec * blocks * g.nr * 4, need_sync = 2 + 4 * (size_t)p->nvec * blocks;  // (2 words used; the rest is the diagnostic build's per-block record)
     if (need_carry > p->lex_carry_doubles || need_sync > p->lex_sync_words) {
       MG_HIP(hipStreamSynchronize(s));
       if (p->d_rq) (void)hipFree(p->d_rq);
@@ -1195,6 +1195,15 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
     return MGCMT_OK;
   }
   return fail(MGCMT_ERR_INVALID, "unknown option");
+}
+
+int mgcmt_lex_wave_stats(mgcmt_plan* p, uint32_t* out, int64_t capacity) {
+  if (!p || !out) return fail(MGCMT_ERR_INVALID, "null argument");
+  if (!p->lex_sync) return fail(MGCMT_ERR_INVALID, "no lexicographic wave sweep has run on this plan");
+  const int64_t n = capacity < (int64_t)p->lex_sync_words ? capacity : (int64_t)p->lex_sync_words;
+  MG_HIP(hipDeviceSynchronize());
+  MG_HIP(hipMemcpy(out, p->lex_sync, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  return MGCMT_OK;
 }
 
 int mgcmt_time_smoother(mgcmt_plan* p, int l, int kind, int nu, double omega, int reps, double* ms_out, void* stream) {
