@@ -57,6 +57,22 @@ typedef unsigned long long u64;
 // operands, so a slot keeps its registers; the wait names every register it releases, so no use moves above it
 // (cdna_hip_programming.md §5.7, form (ii)).
 #if defined(__HIP_DEVICE_COMPILE__)
+// value known to be the same in every lane -> a scalar register (everything derived from it runs on the scalar unit)
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// load at (wave-uniform base) + (32-bit per-lane byte offset) [+ immediate]: no 64-bit address arithmetic per lane
+#define MGCMT_LEX_LOAD_AT(dst, off, base, imm) \
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:" #imm : "+v"(dst) : "v"(off), "s"(base) : "memory")
+#define MGCMT_LEX_LOAD_AT_SC1(dst, off, base) \
+  asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "+v"(dst) : "v"(off), "s"(base) : "memory")
+#else
+__device__ __forceinline__ int uniform(int x) { return x; }
+#define MGCMT_LEX_LOAD_AT(dst, off, base, imm) \
+  (dst) = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (off) + (imm))
+#define MGCMT_LEX_LOAD_AT_SC1(dst, off, base) \
+  (dst) = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(base) + (off))
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
 #define MGCMT_LEX_LOAD(dst, ptr) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory")
 #define MGCMT_LEX_LOAD_SC1(dst, ptr) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(dst) : "v"(ptr) : "memory")
 template <int N>
@@ -146,7 +162,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // block number = order of arrival: whoever this block waits for has started before it
   unsigned ticket = 0;
   if (lane == 0) ticket = atomicAdd(&a.sync[0], 1u);
-  ticket = (unsigned)__shfl((int)ticket, 0);
+  ticket = (unsigned)uniform(__shfl((int)ticket, 0));
   const int q = (int)(ticket / (unsigned)a.nblocks);
   const int J = (int)(ticket % (unsigned)a.nblocks);
   const int nr = a.nr, nc = a.nc;
@@ -252,11 +268,23 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       r_ = load_granule(pr);
       return;
     }
-    if (USE_W) MGCMT_LEX_LOAD(w_, pw);
-    MGCMT_LEX_LOAD(s_, ps);
-    if (USE_S2) MGCMT_LEX_LOAD(s2_, ps2);
-    MGCMT_LEX_LOAD(f_, pf);
-    MGCMT_LEX_LOAD_SC1(r_, pr);
+    const u64* rbase = rec_src + (long)rc * 4;
+    const unsigned roff = (unsigned)(lane & 3) * 8u;
+    const int jw0 = J * 64 - r;  // lane 0's column on that row (wave-uniform)
+    if (jw0 >= 0 && jw0 + 65 <= nc - 1) {  // the window and the two columns right of it inside the grid: one offset
+      const unsigned off = (unsigned)(jw0 + lane) * 8u;
+      if (USE_W) MGCMT_LEX_LOAD_AT(w_, off, row, 0);
+      MGCMT_LEX_LOAD_AT(s_, off, row, 8);
+      if (USE_S2) MGCMT_LEX_LOAD_AT(s2_, off, row, 16);
+      MGCMT_LEX_LOAD_AT(f_, off, frow, 0);
+    } else {
+      const unsigned o0 = (unsigned)j0 * 8u, o1 = (unsigned)j1 * 8u, o2 = (unsigned)j2 * 8u;
+      if (USE_W) MGCMT_LEX_LOAD_AT(w_, o0, row, 0);
+      MGCMT_LEX_LOAD_AT(s_, o1, row, 0);
+      if (USE_S2) MGCMT_LEX_LOAD_AT(s2_, o2, row, 0);
+      MGCMT_LEX_LOAD_AT(f_, o0, frow, 0);
+    }
+    MGCMT_LEX_LOAD_AT_SC1(r_, roff, rbase);
   };
 
   // edge records of the left block: the four granules of a row are read by lanes 0..3 (every lane loads, the address is

@@ -17,8 +17,8 @@ namespace mgcmt {
 #if defined(__HIP__)  // (the host-only emulation build of the tests takes the plain path)
 namespace {
 
-constexpr size_t kChunk = 8u << 20;      // bytes per pinned chunk
-constexpr int kThreads = 4;              // copying threads, two chunks each (one being filled, one in flight)
+constexpr size_t kChunk = 4u << 20;      // bytes per pinned chunk
+constexpr int kThreads = 8;              // copying threads, two chunks each (one being filled, one in flight)
 constexpr size_t kStagedMin = 16u << 20; // smaller transfers take the plain path
 
 struct Lane {
