@@ -270,20 +270,13 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     }
     const u64* rbase = rec_src + (long)rc * 4;
     const unsigned roff = (unsigned)(lane & 3) * 8u;
-    const int jw0 = J * 64 - r;  // lane 0's column on that row (wave-uniform)
-    if (jw0 >= 0 && jw0 + 65 <= nc - 1) {  // the window and the two columns right of it inside the grid: one offset
-      const unsigned off = (unsigned)(jw0 + lane) * 8u;
-      if (USE_W) MGCMT_LEX_LOAD_AT(w_, off, row, 0);
-      MGCMT_LEX_LOAD_AT(s_, off, row, 8);
-      if (USE_S2) MGCMT_LEX_LOAD_AT(s2_, off, row, 16);
-      MGCMT_LEX_LOAD_AT(f_, off, frow, 0);
-    } else {
-      const unsigned o0 = (unsigned)j0 * 8u, o1 = (unsigned)j1 * 8u, o2 = (unsigned)j2 * 8u;
-      if (USE_W) MGCMT_LEX_LOAD_AT(w_, o0, row, 0);
-      MGCMT_LEX_LOAD_AT(s_, o1, row, 0);
-      if (USE_S2) MGCMT_LEX_LOAD_AT(s2_, o2, row, 0);
-      MGCMT_LEX_LOAD_AT(f_, o0, frow, 0);
-    }
+    // ONE straight-line sequence of loads: two alternatives (an unclamped fast form beside this one) meet in a phi, and
+    // the copies that phi costs read registers whose loads are still in flight — and free them for reuse as addresses
+    const unsigned o0 = (unsigned)j0 * 8u, o1 = (unsigned)j1 * 8u, o2 = (unsigned)j2 * 8u;
+    if (USE_W) MGCMT_LEX_LOAD_AT(w_, o0, row, 0);
+    MGCMT_LEX_LOAD_AT(s_, o1, row, 0);
+    if (USE_S2) MGCMT_LEX_LOAD_AT(s2_, o2, row, 0);
+    MGCMT_LEX_LOAD_AT(f_, o0, frow, 0);
     MGCMT_LEX_LOAD_AT_SC1(r_, roff, rbase);
   };
 

@@ -294,7 +294,8 @@ static int comm_common(mgcmt_plan* p, int rank, int nranks, ShardComm** out) {
   c->rank = rank;
   c->nranks = nranks;
   p->comm = c;
-  hipError_t e = hipStreamCreate(&c->comm_stream);
+  // non-blocking: work on it must not serialise with the legacy default stream the cycle may be enqueued on
+  hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_boundary);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_red, sizeof(double) * 64);

@@ -140,3 +140,15 @@ def test_bench_line_contract(capsys, monkeypatch):
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0
     assert abs(out["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-12
     assert len(out["residual_reduction_per_cycle"]) == 10 and out["residual_reduction_per_cycle"][-1] < 1e-3
+
+
+def test_lexwave_isa_keeps_load_destinations_in_place():
+    """The lex pipeline's hand-counted asm loads (kernels_lexwave.hip) are only sound while their destination registers
+    are never copied, spilled or reused as addresses inside the row loop: audited on the gfx950 ISA hipcc emits."""
+    import os, shutil, subprocess, sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "audit_lexwave_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
