@@ -279,6 +279,23 @@ def main(argv=None):
         history.append(float(np.sqrt(plan.dot(0, T, T)) / f_norm))
     out["residual_reduction_per_cycle"] = history
     plan.close()
+    if not args.no_extras:
+        # SURVEY par. 8(f)3: the same cycle on the fourth-order compact 9-point (Mehrstellen) fine-grid operator
+        try:
+            from multigridcmt_amd.operators import mehrstellen_operator
+            m9 = Plan(mehrstellen_operator(g) * (-1.0 / np.pi ** 2), args.lowest, nvec=1, device=0)
+            m9.set_shifts([0.0])
+            m9.upload(0, _lib.SLOT_F, 0, f)
+            steps = 5
+            rec = {"workload": "Mehrstellen 9-point Laplacian %d^2 fp64, V(%d,%d), 1xMI355X" % (g, args.nu, args.nu)}
+            for name_, (k_, om_) in (("wjacobi", kinds["wjacobi"]), ("four_colour", kinds["rb"])):
+                m9.fill(0, _lib.SLOT_V, 0, 0.0)
+                t = time_cycles(m9, steps, 2, lambda: m9.vcycle(args.nu, args.nu, k_, omega=om_, k=1, nu_coarse=args.nu))
+                rec[name_] = {"ms_per_step": t / steps * 1e3, "vcycles_per_s": steps / t, "value": n * sweeps * steps / t / 1e6, "unit": "MLUPS"}
+            out["cycle_mehrstellen"] = rec
+            m9.close()
+        except Exception as e:
+            out["cycle_mehrstellen"] = {"value": None, "error": str(e)}
     if not args.no_extras and g == 16384:
         # BASELINE config 4's workload (32768^2, V(2,2) red-black) on this ONE GPU: the base of the strong-scaling
         # curve `bench.py --gpus N` continues.  Right-hand side: the 16384^2 random field interpolated on the device.

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MGCMT_ABI_VERSION 2
+#define MGCMT_ABI_VERSION 3
 #define MGCMT_MAX_TERMS 4
 #define MGCMT_HALO_ROWS 8 /* rows of halo kept above and below every level's vectors */
 
@@ -106,6 +106,15 @@ int mgcmt_fill(mgcmt_plan* plan, int level, int slot, int vec, double value, voi
 int mgcmt_zero(mgcmt_plan* plan, int level, int slot, int vec, void* stream);
 int mgcmt_copy(mgcmt_plan* plan, int level, int src_slot, int src_vec, int dst_slot, int dst_vec, void* stream);
 int mgcmt_sync(void* stream);
+
+/* Page-locked host memory for the host side of mgcmt_upload / mgcmt_download (and mgcmt_csr_upload / _download).
+ * A transfer to or from pageable memory is staged through a ring of pinned chunks by several host threads
+ * (csrc/transfer.hip); one whose host pointer lies in a buffer of mgcmt_host_alloc — or in any other memory the HIP
+ * runtime knows as page-locked — is a single DMA.  The reference returns fresh arrays from every call
+ * (MGCMTSolver.py:326 `return v`); the drop-in classes return theirs in recycled buffers of this allocator
+ * (multigridcmt_amd/hostmem.py), so a result that is fed back as the next call's v0 never touches pageable memory. */
+int mgcmt_host_alloc(int64_t bytes, void** host_ptr);
+int mgcmt_host_free(void* host_ptr);
 
 /* smoothers on V,F of `level` for vectors 0..k-1 (MGCMTSolver.py:182-246) */
 int mgcmt_smooth(mgcmt_plan* plan, int level, int kind, int nu, double omega, int k, void* stream);

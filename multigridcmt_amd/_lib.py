@@ -18,7 +18,7 @@ OP_A, OP_M = 0, 1
 HALO_ROWS = 8
 MAX_TERMS = 4
 MAX_VEC = 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 OPT_FUSED = 0
 OPT_FUSED_ROWS = 1
 OPT_TAIL = 4
@@ -74,6 +74,8 @@ _SIGNATURES = {
     "mgcmt_zero": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "mgcmt_copy": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mgcmt_sync": (c_int, [c_void_p]),
+    "mgcmt_host_alloc": (c_int, [c_int64, POINTER(c_void_p)]),
+    "mgcmt_host_free": (c_int, [c_void_p]),
     "mgcmt_smooth": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p]),
     "mgcmt_residual_restrict": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "mgcmt_prolong_correct": (c_int, [c_void_p, c_int, c_int, c_void_p]),

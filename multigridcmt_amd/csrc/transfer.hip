@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -14,8 +15,36 @@
 
 namespace mgcmt {
 
+namespace {
+
+// Pinned host buffers handed out by mgcmt_host_alloc (start -> bytes): a transfer whose host side lies inside one is a
+// single DMA, no staging.  (The drop-in classes return their results in such buffers and recycle them, hostmem.py.)
+std::mutex g_pinned_mu;
+std::map<const char*, size_t> g_pinned;
+
+bool in_pinned_registry(const void* host, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_pinned_mu);
+  auto it = g_pinned.upper_bound((const char*)host);
+  if (it == g_pinned.begin()) return false;
+  --it;
+  return (const char*)host + bytes <= it->first + it->second;
+}
+
+}  // namespace
+
 #if defined(__HIP__)  // (the host-only emulation build of the tests takes the plain path)
 namespace {
+
+// page-locked memory the runtime knows about (ours, or a caller's own: hipHostMalloc / hipHostRegister / a pinned tensor)
+bool is_pinned(const void* host, size_t bytes) {
+  if (in_pinned_registry(host, bytes)) return true;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, host) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
 
 constexpr size_t kChunk = 4u << 20;      // bytes per pinned chunk
 constexpr int kThreads = 8;              // copying threads, two chunks each (one being filled, one in flight)
@@ -113,7 +142,7 @@ int transfer(int device, bool upload, void* dev, void* host, size_t bytes, hipSt
     const char* e = getenv("MGCMT_STAGED_TRANSFER");  // "0": always the plain hipMemcpy path (A/B measurements)
     return !(e && e[0] == '0');
   }();
-  if (enabled && bytes >= kStagedMin) {
+  if (enabled && bytes >= kStagedMin && !is_pinned(host, bytes)) {
     std::lock_guard<std::mutex> lock(g_ring.mu);
     if (ring_init(device)) {
       std::atomic<int> error{0};
@@ -134,3 +163,42 @@ int transfer(int device, bool upload, void* dev, void* host, size_t bytes, hipSt
 }
 
 }  // namespace mgcmt
+
+extern "C" {
+
+int mgcmt_host_alloc(int64_t bytes, void** out) {
+  using namespace mgcmt;
+  if (!out || bytes <= 0) return fail(MGCMT_ERR_INVALID, "mgcmt_host_alloc: bad arguments");
+  void* p = nullptr;
+#if defined(__HIP__)
+  MG_HIP(hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
+#else
+  p = malloc((size_t)bytes);
+  if (!p) return fail(MGCMT_ERR_NOMEM, "mgcmt_host_alloc: out of memory");
+#endif
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    g_pinned[(const char*)p] = (size_t)bytes;
+  }
+  *out = p;
+  return MGCMT_OK;
+}
+
+int mgcmt_host_free(void* p) {
+  using namespace mgcmt;
+  if (!p) return MGCMT_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    auto it = g_pinned.find((const char*)p);
+    if (it == g_pinned.end()) return fail(MGCMT_ERR_INVALID, "mgcmt_host_free: not a buffer of mgcmt_host_alloc");
+    g_pinned.erase(it);
+  }
+#if defined(__HIP__)
+  MG_HIP(hipHostFree(p));
+#else
+  free(p);
+#endif
+  return MGCMT_OK;
+}
+
+}  // extern "C"

@@ -140,6 +140,29 @@ def laplacian_operator(n, dimension="1d"):
     return StructuredOperator("2d", n, [(tri_identity(n), tri_laplacian(n)), (tri_laplacian(n), tri_identity(n))])
 
 
+def mehrstellen_operator(n):
+    """The compact fourth-order ("Mehrstellen") 9-point Laplacian the reference's report proposes as the next fine-grid
+    stencil (SURVEY.md par. 8(f)3; not in the reference's code):  1/(6 h^2) [[1, 4, 1], [4, -20, 4], [1, 4, 1]]
+    =  I (x) L + L (x) I + (h^2 / 6) L (x) L  with the 1-D operator L of MGCMTStencilMaker.py:17-21 (h = 1/n, as there).
+    Three Toeplitz terms: the fused kernels take it as a constant 9-point operator on every level."""
+    n = int(n)
+    h = 1. / n
+    L = tri_laplacian(n)
+    return StructuredOperator("2d", n, [(tri_identity(n), L.copy()), (L.copy(), tri_identity(n)), (L * (h ** 2 / 6.0), L.copy())])
+
+
+def mehrstellen_mass(n):
+    """M = I + (h^2 / 12) (I (x) L + L (x) I): the right-hand-side operator that goes with mehrstellen_operator —
+    Delta_9 u = M (Delta u) + O(h^4), so  -Delta u = f  becomes  Delta_9 u = -M f, and  -Delta u = lambda u  the
+    generalised problem  -Delta_9 u = lambda M u."""
+    n = int(n)
+    h = 1. / n
+    L = tri_laplacian(n) * (h ** 2 / 12.0)
+    y = L.copy()
+    y[1] += 1.0
+    return StructuredOperator("2d", n, [(tri_identity(n), y), (L.copy(), tri_identity(n))])
+
+
 def identity_operator(n, dimension="1d"):
     """sparse.eye(N) as a structured operator (the mass matrix M of rqmin, RQMin.py:18)."""
     n = int(n)
@@ -268,9 +291,16 @@ def recognise(A, dimension=None):
                 ok = np.abs(np.outer(p_, q_) - rest).max() <= 64 * np.finfo(float).eps * scale
                 extra = (p_, q_)
         if not ok:
-            raise UnrecognisedOperator(
-                "2-D operator is not of the form I (x) Y + X (x) I (+ one product potential p (x) q on the diagonal); "
-                "the HIP path handles scaled/shifted Laplacians with separable or square-well potentials only")
+            op = _constant_nine_point(M, g)
+            if op is None:
+                raise UnrecognisedOperator(
+                    "2-D operator is neither of the form I (x) Y + X (x) I (+ one product potential p (x) q on the diagonal) "
+                    "nor a constant 9-point stencil; the HIP path handles scaled/shifted Laplacians with separable or "
+                    "square-well potentials and constant compact stencils only")
+            if len(_CACHE) > 64:
+                _CACHE.clear()
+            _CACHE[key] = (A, op)
+            return op
         Y = np.zeros((3, g))
         Y[0], Y[1], Y[2] = w[0], yd, e[0]
         X = np.zeros((3, g))
@@ -287,6 +317,41 @@ def recognise(A, dimension=None):
         _CACHE.clear()
     _CACHE[key] = (A, op)
     return op
+
+
+def _toeplitz_tri(lo, di, up, g):
+    t = np.zeros((3, g))
+    t[0, 1:], t[1], t[2, :-1] = lo, di, up
+    return t
+
+
+def _constant_nine_point(M, g):
+    """A constant 3 x 3 stencil c on the g x g grid (zero Dirichlet truncation) — e.g. the Mehrstellen Laplacian, shifted
+    or scaled — as  sum_a E_a (x) T(c[a, :])  with E_a the unit sub-/main/super-diagonal: exact, no arithmetic on the
+    entries (rows 0 and 2 of a stencil that is symmetric top to bottom share one term).  None if M is not of that form."""
+    if g < 3:
+        return None
+    r0 = g + 1
+    row = M.getrow(r0)
+    c = np.zeros((3, 3))
+    for col, val in zip(row.indices, row.data):
+        a, b = col // g - 1 + 1, col % g - 1 + 1
+        if not (0 <= a <= 2 and 0 <= b <= 2):
+            return None
+        c[a, b] = val
+    if np.array_equal(c[0], c[2]):
+        terms = [(_toeplitz_tri(1.0, 0.0, 1.0, g), _toeplitz_tri(*c[0], g)), (tri_identity(g), _toeplitz_tri(*c[1], g))]
+    else:
+        terms = [(_toeplitz_tri(1.0, 0.0, 0.0, g), _toeplitz_tri(*c[0], g)), (tri_identity(g), _toeplitz_tri(*c[1], g)),
+                 (_toeplitz_tri(0.0, 0.0, 1.0, g), _toeplitz_tri(*c[2], g))]
+    terms = [(x, y) for x, y in terms if y.any()]
+    if not terms:
+        return None
+    B = sum(sp.kron(tri_to_sparse(x), tri_to_sparse(y), format="csr") for x, y in terms).tocsr()
+    D = (M - B).tocsr()
+    if D.nnz and np.abs(D.data).max() != 0.0:
+        return None
+    return StructuredOperator("2d", g, terms)
 
 
 def tag_structured(matrix, op):

@@ -9,7 +9,7 @@ from ctypes import c_double, c_int, c_int64, c_void_p
 
 import numpy as np
 
-from . import _lib
+from . import _lib, hostmem
 from ._lib import OP_A, OP_M, SLOT_F, SLOT_T, SLOT_V, SLOT_W, PlanDesc, as_dp, check
 
 
@@ -96,7 +96,7 @@ class Plan:
         check(_lib.lib().mgcmt_upload(self._h, level, slot, vec, as_dp(a), a.size, stream))
 
     def download(self, level, slot, vec, stream=None):
-        out = np.empty(self.size(level), dtype=np.float64)
+        out = hostmem.empty(self.size(level))  # (large results: recycled page-locked memory, one DMA)
         check(_lib.lib().mgcmt_download(self._h, level, slot, vec, as_dp(out), out.size, stream))
         return out
 

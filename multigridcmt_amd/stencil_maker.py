@@ -12,7 +12,7 @@ import math
 import numpy as np
 import scipy.sparse as spsparse
 
-from .operators import laplacian_operator
+from .operators import laplacian_operator, mehrstellen_mass, mehrstellen_operator
 
 
 def _power_of_two(x):
@@ -37,6 +37,17 @@ class MGCMTStencilMaker:
             one_d = self.laplacian(n, dimension="1d")
             return spsparse.kronsum(one_d, one_d)
         return None
+
+    def mehrstellen(self, n, matrix_free=False):
+        """Not in the reference: the fourth-order compact 9-point Laplacian its report names as the next stencil
+        (operators.mehrstellen_operator), as a sparse matrix like laplacian(n, "2d") or matrix-free."""
+        op = mehrstellen_operator(int(n))
+        return op if matrix_free else op.tocsr().tocsc()
+
+    def mehrstellen_mass(self, n, matrix_free=False):
+        """The operator M on the right-hand side of the Mehrstellen discretisation (operators.mehrstellen_mass)."""
+        op = mehrstellen_mass(int(n))
+        return op if matrix_free else op.tocsr().tocsc()
 
     def interpolation(self, old_gridsize, new_gridsize, dimension="1d"):
         """MGCMTStencilMaker.py:27-54.  Ratio m = new/old = 2^p: column J is the hat of half-width m

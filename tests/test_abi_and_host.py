@@ -140,6 +140,7 @@ def test_bench_line_contract(capsys, monkeypatch):
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0
     assert abs(out["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-12
     assert len(out["residual_reduction_per_cycle"]) == 10 and out["residual_reduction_per_cycle"][-1] < 1e-3
+    assert out["cycle_mehrstellen"]["four_colour"]["ms_per_step"] > 0 and out["cycle_mehrstellen"]["wjacobi"]["value"] > 0
 
 
 def test_lexwave_isa_keeps_load_destinations_in_place():
@@ -152,3 +153,46 @@ def test_lexwave_isa_keeps_load_destinations_in_place():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "audit_lexwave_isa.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_result_arrays_recycle_their_page_locked_buffers(backend, monkeypatch):
+    """hostmem.empty: an ordinary ndarray over a buffer of mgcmt_host_alloc; the buffer returns to the free list when the
+    last view dies; the limit and the size threshold fall back to numpy.empty."""
+    import gc
+    from multigridcmt_amd import hostmem
+    hostmem.drain()
+    base = hostmem.stats()
+    n = (hostmem.MIN_BYTES // 8) + 5
+    a = hostmem.empty(n)
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.size == n and a.flags.writeable and a.flags.c_contiguous
+    a[:] = np.arange(n)
+    address = a.ctypes.data
+    view = a[3:9]
+    del a
+    gc.collect()
+    assert hostmem.stats()["free_buffers"] == 0 and view[0] == 3.0          # a view keeps the buffer
+    del view
+    gc.collect()
+    assert hostmem.stats()["free_buffers"] == 1
+    b = hostmem.empty(n)
+    assert b.ctypes.data == address and hostmem.stats()["reused"] == base["reused"] + 1
+    small = hostmem.empty(16)
+    assert small.base is None                                               # below the threshold: numpy's own memory
+    monkeypatch.setenv("MGCMT_PINNED_POOL_BYTES", "0")
+    assert hostmem.empty(n).base is None
+    monkeypatch.setenv("MGCMT_PINNED_POOL_BYTES", str(8 * n + 8))           # room for exactly one buffer of this size
+    c = hostmem.empty(n)                                                    # b holds it: fallback
+    assert c.base is None
+    del b
+    gc.collect()
+    d = hostmem.empty(2 * n)                                                # does not fit even after trimming
+    assert d.base is None
+    e = hostmem.empty(n)
+    assert e.ctypes.data == address
+    del e
+    gc.collect()
+    hostmem.drain()
+    assert hostmem.stats()["pinned_bytes"] == 0
+    lib = _lib.lib()
+    assert lib.mgcmt_host_free(ctypes.c_void_p(12345)) != 0                  # not one of ours
+    assert lib.mgcmt_host_alloc(0, ctypes.byref(ctypes.c_void_p())) != 0
