@@ -24,7 +24,7 @@
 //
 // Covers the constant-coefficient operators (the scaled / shifted Laplacian and its Galerkin coarsenings, whose
 // factors are Toeplitz except for their last diagonal entry); other operators and small grids keep kernels_lex.hip.
-#include "mgcmt_internal.h"
+#include "lex_util.h"
 
 namespace mgcmt {
 
@@ -48,111 +48,6 @@ struct LexWaveArgs {
   unsigned* sync;             // [0] ticket, [1] error
   long carry_stride;          // granules per vector
 };
-
-typedef unsigned long long u64;
-
-// Loads of the row loop are hand-counted: issued as asm (the compiler does not see them, so it neither waits for them nor
-// drains them), consumed behind ONE s_waitcnt vmcnt(N) per row whose N = the memory operations issued since the youngest
-// value that row needs (vector-memory operations complete in order, stores included).  The destinations are read-write
-// operands, so a slot keeps its registers; the wait names every register it releases, so no use moves above it
-// (cdna_hip_programming.md §5.7, form (ii)).
-#if defined(__HIP_DEVICE_COMPILE__)
-// value known to be the same in every lane -> a scalar register (everything derived from it runs on the scalar unit)
-__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
-// load at (wave-uniform base) + (32-bit per-lane byte offset) [+ immediate]: no 64-bit address arithmetic per lane
-#define MGCMT_LEX_LOAD_AT(dst, off, base, imm) \
-  asm volatile("global_load_dwordx2 %0, %1, %2 offset:" #imm : "+v"(dst) : "v"(off), "s"(base) : "memory")
-#define MGCMT_LEX_LOAD_AT_SC1(dst, off, base) \
-  asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "+v"(dst) : "v"(off), "s"(base) : "memory")
-#else
-__device__ __forceinline__ int uniform(int x) { return x; }
-#define MGCMT_LEX_LOAD_AT(dst, off, base, imm) \
-  (dst) = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (off) + (imm))
-#define MGCMT_LEX_LOAD_AT_SC1(dst, off, base) \
-  (dst) = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(base) + (off))
-#endif
-
-#if defined(__HIP_DEVICE_COMPILE__)
-#define MGCMT_LEX_LOAD(dst, ptr) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory")
-#define MGCMT_LEX_LOAD_SC1(dst, ptr) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(dst) : "v"(ptr) : "memory")
-template <int N>
-__device__ __forceinline__ void wait_loads(double& a, double& b, double& c, double& d, double& e, double& f, double& g, unsigned long long& r) {
-  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(r) : "n"(N) : "memory");
-}
-__device__ __forceinline__ void drain_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#else
-#define MGCMT_LEX_LOAD(dst, ptr) (dst) = *(ptr)
-#define MGCMT_LEX_LOAD_SC1(dst, ptr) (dst) = *(ptr)
-template <int N>
-__device__ __forceinline__ void wait_loads(double&, double&, double&, double&, double&, double&, double&, unsigned long long&) {}
-__device__ __forceinline__ void drain_loads() {}
-#endif
-
-#if defined(__HIP_DEVICE_COMPILE__)
-template <int CTRL>
-__device__ __forceinline__ double dpp(double v) {
-  const u64 u = __builtin_bit_cast(u64, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((u64)hi << 32) | lo);
-}
-template <int D>
-__device__ __forceinline__ double row_shr(double v, int) { return dpp<0x110 + D>(v); }    // lane - D inside rows of 16 (else 0)
-__device__ __forceinline__ double bcast15(double v, int) { return dpp<0x142>(v); }         // lane 15 of the previous row of 16
-__device__ __forceinline__ double bcast31(double v, int) { return dpp<0x143>(v); }         // lane 31
-__device__ __forceinline__ double from_left(double v, int) { return dpp<0x138>(v); }       // lane - 1 (lane 0: 0)
-__device__ __forceinline__ double from_right(double v, int) { return dpp<0x130>(v); }      // lane + 1 (lane 63: 0)
-__device__ __forceinline__ u64 lane_bits(u64 u, int k) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, k);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), k);
-  return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 vote(bool x) { return __ballot(x); }
-__device__ __forceinline__ unsigned load_word(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void store_word(unsigned* p, unsigned x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ u64 load_granule(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void store_granule(u64* p, u64 x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ u64 now_ticks() { return wall_clock64(); }  // 100 MHz
-__device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(1); }
-#else
-// host-side stand-ins (the emulator runs one workgroup at a time, in block order: a block never has to wait)
-template <int D>
-__device__ __forceinline__ double row_shr(double v, int lane) { const double r = __shfl_up(v, D); return (lane & 15) >= D ? r : 0.0; }
-__device__ __forceinline__ double bcast15(double v, int lane) { return __shfl(v, ((lane & ~15) - 1) & 63); }
-__device__ __forceinline__ double bcast31(double v, int) { return __shfl(v, 31); }
-__device__ __forceinline__ double from_left(double v, int lane) { const double r = __shfl_up(v, 1); return lane >= 1 ? r : 0.0; }
-__device__ __forceinline__ double from_right(double v, int lane) { const double r = __shfl_down(v, 1); return lane <= 62 ? r : 0.0; }
-__device__ __forceinline__ u64 lane_bits(u64 u, int k) { return (u64)__shfl((long long)u, k); }
-__device__ __forceinline__ u64 vote(bool x) {
-  u64 m = 0;
-  for (int k = 0; k < 64; ++k) m |= (u64)(__shfl(x ? 1 : 0, k) & 1) << k;
-  return m;
-}
-__device__ __forceinline__ unsigned load_word(const unsigned* p) { return *p; }
-__device__ __forceinline__ void store_word(unsigned* p, unsigned x) { *p = x; }
-__device__ __forceinline__ u64 load_granule(const u64* p) { return *p; }
-__device__ __forceinline__ void store_granule(u64* p, u64 x) { *p = x; }
-__device__ __forceinline__ u64 now_ticks() { return 0; }
-__device__ __forceinline__ void nap() {}
-#endif
-
-template <bool B>
-struct Checked {
-  static constexpr bool value = B;
-};
-template <int N>
-struct Int {
-  static constexpr int value = N;
-};
-template <int N, int I = 0, class F>
-__device__ __forceinline__ void for_slots(F&& f) {
-  if constexpr (I < N) {
-    f(Int<I>{});
-    for_slots<N, I + 1>(f);
-  }
-}
-
-constexpr u64 kTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz counter: a stuck pipeline gives up
 
 // FIVE: constant 5-point operator (no corner terms, no special last row / column); OWN: the sweep uses the point's own
 // old value (alpha != 0: the homogeneous SOR recurrence)
@@ -229,8 +124,15 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   constexpr int kOps = kLoads + 2;                                 // ... + the row's store and its record's store
   constexpr int kSlots = kOps <= 5 ? 12 : (kOps == 6 ? 10 : 9);    // pipeline slots = rows in flight + the one in use
   constexpr int kDepth = kSlots - 1;
-  constexpr int kWaitN = (kDepth - 1) * kOps;                      // rows i+2 .. i+kDepth may still be in flight
+  // The left block's record of row r is asked for kRec rows ahead only — not kDepth + 1 like the old values: a block can
+  // run no closer behind its left neighbour than the distance at which its prefetched records come back complete, and the
+  // sum of those lags over the blocks is the sweep's start-up time.  A step issues [row store, record store, record load of
+  // row i + kRec, old values of row i + kDepth + 1]; loads complete in order, so the wait of step i — for the record of row
+  // i, issued kRec steps ago — lets only what was issued after it stay in flight.
+  constexpr int kRec = 4;
+  constexpr int kWaitN = (kLoads - 1) + (kRec - 1) * kOps;
   static_assert(kWaitN <= 63, "vmcnt is a 6-bit counter");
+  static_assert(kRec <= kDepth, "the old values of rows i, i + 1 are older than the record of row i");
   double Wv[kSlots], Sv[kSlots], S2v[kSlots], Fv[kSlots];
   u64 Rv[kSlots];
 #pragma unroll
@@ -242,46 +144,50 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     Rv[d] = 0;
   }
   const u64* rec_src = J > 0 ? left_rec : my_rec;  // (block 0 has no left neighbour: any valid address, result unused)
-  // issue the loads of row r into slot SL: addresses clamped into the row, masks applied when the row is used.
+  // issue the loads of row r's old values into slot SL: addresses clamped into the row, masks applied when the row is used.
   // PLAIN: compiler-visible loads (the prologue, which the compiler may schedule and wait for as it likes); otherwise the
   // hand-counted asm loads of the row loop
-  auto issue_row = [&](auto plain, auto slot, int r) __attribute__((always_inline)) {
+  const int lane8 = lane * 8, hi8 = (nc - 1) * 8;
+  auto issue_old = [&](auto plain, auto slot, int r) __attribute__((always_inline)) {
     constexpr int SL = decltype(slot)::value;
     const int rr = r < nr ? r : nr;
     const double* row = v + (long)rr * nc;
     const double* frow = f + (long)rr * nc;
-    const int jw = J * 64 - r + lane;
-    int j0 = jw, j1 = jw + 1, j2 = jw + 2;
-    j0 = j0 < 0 ? 0 : (j0 > nc - 1 ? nc - 1 : j0);
-    j1 = j1 < 0 ? 0 : (j1 > nc - 1 ? nc - 1 : j1);
-    j2 = j2 < 0 ? 0 : (j2 > nc - 1 ? nc - 1 : j2);
+    const int jw8 = (J * 64 - r) * 8 + lane8;  // byte offset of this lane's column on that row
+    const unsigned o0 = (unsigned)clamp0(jw8, hi8), o1 = (unsigned)clamp0(jw8 + 8, hi8), o2 = (unsigned)clamp0(jw8 + 16, hi8);
     double &w_ = Wv[SL], &s_ = Sv[SL], &s2_ = S2v[SL], &f_ = Fv[SL];  // (named here: a variable that only an asm
-    u64& r_ = Rv[SL];                                                   //  statement mentions is not captured)
-    const double *pw = row + j0, *ps = row + j1, *ps2 = row + j2, *pf = frow + j0;
-    const int rc = r > nr - 1 ? nr - 1 : r;
-    const u64* pr = rec_src + (long)rc * 4 + (lane & 3);
+                                                                       //  statement mentions is not captured)
     if (decltype(plain)::value) {
-      if (USE_W) w_ = *pw;
-      s_ = *ps;
-      if (USE_S2) s2_ = *ps2;
-      f_ = *pf;
-      r_ = load_granule(pr);
+      if (USE_W) w_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + o0);
+      s_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + o1);
+      if (USE_S2) s2_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + o2);
+      f_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(frow) + o0);
       return;
     }
-    const u64* rbase = rec_src + (long)rc * 4;
-    const unsigned roff = (unsigned)(lane & 3) * 8u;
     // ONE straight-line sequence of loads: two alternatives (an unclamped fast form beside this one) meet in a phi, and
     // the copies that phi costs read registers whose loads are still in flight — and free them for reuse as addresses
-    const unsigned o0 = (unsigned)j0 * 8u, o1 = (unsigned)j1 * 8u, o2 = (unsigned)j2 * 8u;
     if (USE_W) MGCMT_LEX_LOAD_AT(w_, o0, row, 0);
     MGCMT_LEX_LOAD_AT(s_, o1, row, 0);
     if (USE_S2) MGCMT_LEX_LOAD_AT(s2_, o2, row, 0);
     MGCMT_LEX_LOAD_AT(f_, o0, frow, 0);
-    MGCMT_LEX_LOAD_AT_SC1(r_, roff, rbase);
+  };
+  // ... and of row r's edge record (lanes 0..3 matter; every lane loads)
+  const unsigned roff = (unsigned)(lane & 3) * 8u;
+  auto issue_rec = [&](auto plain, auto slot, int r) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot)::value;
+    u64& r_ = Rv[SL];
+    const int rc = r > nr - 1 ? nr - 1 : r;
+    const u64* rbase = rec_src + (long)rc * 4;
+    if (decltype(plain)::value) {
+      r_ = load_granule(rbase + (lane & 3));
+      return;
+    }
+    const unsigned ro = roff;  // (a use outside the asm statement: see above)
+    MGCMT_LEX_LOAD_AT_SC1(r_, ro, rbase);
   };
 
   // edge records of the left block: the four granules of a row are read by lanes 0..3 (every lane loads, the address is
-  // clamped), kDepth + 1 rows before they are needed, with the row's old values; the slow path asks again, visibly
+  // clamped), kRec rows before they are needed; the slow path asks again, visibly
   auto load_record = [&](int row) __attribute__((always_inline)) {
     const int rc = row < 0 ? 0 : (row > nr - 1 ? nr - 1 : row);
     return load_granule(rec_src + (long)rc * 4 + (lane & 3));
@@ -326,10 +232,23 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     }
   };
 
-  // fill the pipeline: rows i0 .. i0 + kDepth, with loads the compiler sees (it waits for them before the row loop's
+  // fill the pipeline: old values of rows i0 .. i0 + kDepth, records of rows i0 .. i0 + kRec - 1, with loads the compiler sees (it waits for them before the row loop's
   // first asm statement reads their registers; from then on nothing but the loop's own asm touches a slot)
-  for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) { issue_row(Checked<true>{}, sl, i0 + decltype(sl)::value); });
+  for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) { issue_old(Checked<true>{}, sl, i0 + decltype(sl)::value); });
+  for_slots<kRec>([&](auto sl) __attribute__((always_inline)) { issue_rec(Checked<true>{}, sl, i0 + decltype(sl)::value); });
   drain_loads();
+  // The compiler does not know that the drain above completed its loads.  Left at that, it carries "slot k's load may be
+  // pending" around the loop and puts its own s_waitcnt vmcnt(3 (kSlots - 1 - k)) before the first read of slot k in EVERY
+  // trip — on the hardware's counter, which also counts the hand-issued loads, that drains the pipeline towards the end
+  // of each trip.  One visible use per slot register here makes it wait once, now, for nothing.
+#pragma unroll
+  for (int d = 0; d < kSlots; ++d) {
+    settle(Wv[d]);
+    settle(Sv[d]);
+    settle(S2v[d]);
+    settle(Fv[d]);
+    settle(Rv[d]);
+  }
 
   double prev = 0.0;            // new values of the previous row (this lane's column + 1 there)
   double c1p = 0.0, c2p = 0.0;  // the left block's edge values on the previous row
@@ -354,7 +273,8 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     // holds column 0 on it has finished it — so they must not be slower than the interior rows.
     const bool INTERIOR = jmin >= 1 && jmin + 64 <= nc - (FIVE ? 1 : 2);
     const bool FAST = FIVE || i < nr - 1;  // (every row but a 9-point level's last one)
-    // rows i and i + 1 have landed when at most the loads and stores of the kDepth - 1 rows behind them are in flight
+    // the record of row i — and everything issued before it: the old values of rows i and i + 1 — has landed when at most
+    // what was issued after it is in flight
     wait_loads<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH]);
     double own = Wv[PH], e = Sv[PH], fv = Fv[PH];
     double sw = Wv[NEXT], s = Sv[NEXT], se = S2v[NEXT];
@@ -487,14 +407,16 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     }
     double x = fma(qmul, c1, p);
     if (!valid) x = 0.0;
-    if (valid) v[(long)i * nc + j] = x;
+    // (wave-uniform row base + 32-bit lane offset: one scalar add per row, no 64-bit lane arithmetic)
+    if (valid) *reinterpret_cast<double*>(reinterpret_cast<char*>(v + (long)i * nc + jmin) + (unsigned)lane8) = x;
     {  // the row's edge record: {tag, half a double} granules, ONE store instruction (lanes 60..63; FIVE: 62, 63)
       const double t1 = from_right(x, lane);   // lane 62: x63, lane 61: x62
       const double t2 = from_right(t1, lane);  // lane 60: x62
       const double src = lane == 63 ? x : (lane == 60 ? t2 : t1);
       const u64 bits = __builtin_bit_cast(u64, src);
       const u64 word = (1ull << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xffffffffull));
-      if (lane >= (FIVE ? 62 : 60)) store_granule(my_rec + (long)i * 4 + (lane - 60), word);
+      if (lane >= (FIVE ? 62 : 60))
+        store_granule(reinterpret_cast<u64*>(reinterpret_cast<char*>(my_rec + (long)i * 4 - 60) + (unsigned)lane8), word);
     }
     prev = x;
     c1p = c1;
@@ -503,7 +425,8 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     // loads land in the very registers the slot had (issued earlier, the old and the new value would be alive together, the
     // slots would rotate through registers, and the copies that restore them at the loop's latch would read registers whose
     // loads are still in flight)
-    issue_row(Checked<false>{}, ph, i + kDepth + 1);
+    issue_rec(Checked<false>{}, Int<(PH + kRec) % kSlots>{}, i + kRec);
+    issue_old(Checked<false>{}, ph, i + kDepth + 1);
   };
   // ONE loop over the block's rows, kSlots rows per trip with compile-time phases; the last trip skips the rows behind i1
   // (a skipped step issues nothing, and nothing behind it consumes)

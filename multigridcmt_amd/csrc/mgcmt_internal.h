@@ -68,6 +68,12 @@ bool lex_wave_supported(const KGrid& g, const KOp& op);
 long lex_wave_blocks(const KGrid& g);
 void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta, double wU,
                      double wL, int k, double* carry, unsigned* sync);
+// ... and as a wavefront over bands of 63 rows (kernels_lexband.hip; same operators and grids).  carry: k *
+// lex_band_count(g) * lex_band_stride(g) eight-byte granules; sync as above
+long lex_band_count(const KGrid& g);
+long lex_band_stride(const KGrid& g);
+void launch_lex_band(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta, double wU,
+                     double wL, int k, double* carry, unsigned* sync);
 
 // fused row-streaming passes (fused_kernel.h, kernels_fused*.hip): vin -> vout with nsweep sweeps of weighted
 // Jacobi or multicolour Gauss-Seidel.  mode & 3: 0 plain, 1 prolong+correct first (coarse = correction), 2

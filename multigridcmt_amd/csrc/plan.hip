@@ -280,8 +280,10 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
   const KGrid g = p->kgrid(l);
   const KOp& op = p->levels[l].dA.k;
   if (p->use_lex_wave && p->levels[l].nr == p->levels[l].gr && lex_wave_supported(g, op)) {
+    const bool band = p->use_lex_wave == 2;
     const size_t blocks = (size_t)lex_wave_blocks(g);
-    const size_t need_carry = (size_t)p->nvec * blocks * g.nr * 4, need_sync = 2 + 4 * (size_t)p->nvec * blocks;  // (2 words used; the rest is the diagnostic build's per-block record)
+    const size_t need_scan = (size_t)p->nvec * blocks * g.nr * 4, need_band = (size_t)p->nvec * lex_band_count(g) * lex_band_stride(g);
+    const size_t need_carry = band ? need_band : need_scan, need_sync = 2 + 4 * (size_t)p->nvec * blocks;  // (2 words used; the rest is the diagnostic build's per-block record)
     if (need_carry > p->lex_carry_doubles || need_sync > p->lex_sync_words) {
       MG_HIP(hipStreamSynchronize(s));
       if (p->d_rq) (void)hipFree(p->d_rq);
@@ -296,7 +298,8 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
       p->lex_carry_doubles = need_carry;
       p->lex_sync_words = need_sync;
     }
-    launch_lex_wave(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync);
+    if (band) launch_lex_band(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync);
+    else launch_lex_wave(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync);
     p->lex_wave_used = true;
     return MGCMT_OK;
   }
@@ -1180,7 +1183,7 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
     return MGCMT_OK;
   }
   if (option == MGCMT_OPT_LEX_WAVE) {
-    p->use_lex_wave = value != 0;
+    p->use_lex_wave = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     p->graphs_invalidate();
     return MGCMT_OK;
   }

@@ -80,7 +80,7 @@ struct mgcmt_plan {
   bool use_graph = true;
   long fused_rows = 0;            // tuning: rows per wave chunk of the fused passes, 0 = automatic
   mgcmt::ShardComm* comm = nullptr;  // communicator of a sharded plan (sharded.hip), owned
-  bool use_lex_wave = true;       // lexicographic sweeps as a pipeline of waves where kernels_lexwave.hip covers the level
+  int use_lex_wave = 1;           // lexicographic sweeps on the whole chip where the level is covered: 1 = skewed column blocks with a scan per row (kernels_lexwave.hip), 2 = row bands swept as a wavefront (kernels_lexband.hip); 0 = one workgroup
   double* lex_carry = nullptr;    // its scratch (grown on demand)
   unsigned* lex_sync = nullptr;
   size_t lex_carry_doubles = 0, lex_sync_words = 0;

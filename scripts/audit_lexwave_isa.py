@@ -1,40 +1,48 @@
-"""ISA audit of the lexicographic wave pipeline (kernels_lexwave.hip).
+"""ISA audit of the lexicographic pipelines (kernels_lexwave.hip, kernels_lexband.hip).
 
 The row loop's loads are asm statements the compiler does not count: nothing waits for them but the kernel's own
 s_waitcnt.  That is only sound while every destination register of such a load stays the slot's register for the whole
 loop.  If the compiler ever routes a destination through a temporary (a phi between two alternative load sequences, a
 spill, a re-materialised copy), the temporary is read while its load is in flight and is then reused — as an address
 in the worst case, which is a memory fault on the GPU.  This script compiles the kernel for gfx950 and checks, for the
-region after the prologue's last vmcnt(0), that no destination of a hand-counted load is
+row loop (from its header on), that no destination of a hand-counted load is
   - the source of a plain v_mov_b32 (a copy),
   - the address operand of any global load / store,
   - stored to scratch.
-Exit status 0 = clean.  Usage: python scripts/audit_lexwave_isa.py [file.s]"""
+Exit status 0 = clean.  Usage: python scripts/audit_lexwave_isa.py [file.s [kernel name]]"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "multigridcmt_amd", "csrc")
 
 
-def compile_isa(out):
+KERNELS = {"k_lex_wave": "kernels_lexwave.hip", "k_lex_band": "kernels_lexband.hip"}
+
+
+def compile_isa(out, source="kernels_lexwave.hip"):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-           "-ffp-contract=off", "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "kernels_lexwave.hip")]
+           "-ffp-contract=off", "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, source)]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
-def audit(path):
+def audit(path, kernel="k_lex_wave"):
     lines = open(path).read().split("\n")
-    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN5mgcmt.*k_lex_wave.*:", l)]
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN5mgcmt.*" + kernel + r".*:", l)]
     report = []
     for k, s in enumerate(starts):
         body = lines[s:(starts[k + 1] if k + 1 < len(starts) else len(lines))]
-        counted = [i for i, l in enumerate(body) if (m := re.search(r"s_waitcnt vmcnt\((\d+)\)", l)) and int(m.group(1)) >= 20]
+        counted = [i for i, l in enumerate(body) if (m := re.search(r"s_waitcnt vmcnt\((\d+)\)", l)) and int(m.group(1)) >= 10
+                   and "#ASMSTART" in body[i - 1]]
         if not counted:
             report.append((k, 0, ["no hand-counted wait found"]))
             continue
-        prologue_end = [i for i, l in enumerate(body[:counted[0]]) if "s_waitcnt vmcnt(0)" in l][-1]
-        loop = [l.strip() for l in body[prologue_end:]]
+        # the row loop: from its header (the last depth-1 loop header before the first hand-counted wait) to the end
+        headers = [i for i, l in enumerate(body[:counted[0]]) if re.match(r"^\.LBB\d+_\d+:", l) and "Loop Header: Depth=1" in l]
+        if not headers:
+            report.append((k, 0, ["no loop header before the first hand-counted wait"]))
+            continue
+        loop = [l.strip() for l in body[headers[-1]:]]
         dests = set()
         for t in loop:
             m = re.search(r"global_load_dwordx2 v\[(\d+):(\d+)\], v\d+, s\[", t)
@@ -57,29 +65,38 @@ def audit(path):
             m = re.search(r"scratch_store\S* .*?v\[?(\d+)", t)
             if m and int(m.group(1)) in dests:
                 bad.append(t)
+        # the compiler's own waits inside the loop must be full drains of the slow path only: a partial one (vmcnt(N), N > 1)
+        # means it believes a load pending on a slot register and throttles the pipeline on the hardware's counter
+        for i, t in enumerate(loop):
+            m = re.search(r"s_waitcnt vmcnt\((\d+)\)", t)
+            if m and int(m.group(1)) > 1 and "#ASMSTART" not in loop[i - 1]:
+                bad.append("compiler-inserted " + t)
         report.append((k, len(dests), bad))
     return report
 
 
 def main():
+    reports = []
     if len(sys.argv) > 1:
-        path = sys.argv[1]
-        rep = audit(path)
+        kernel = sys.argv[2] if len(sys.argv) > 2 else "k_lex_wave"
+        reports.append((kernel, audit(sys.argv[1], kernel)))
     else:
         with tempfile.TemporaryDirectory() as d:
-            path = os.path.join(d, "lexwave.s")
-            compile_isa(path)
-            rep = audit(path)
+            for kernel, source in KERNELS.items():
+                path = os.path.join(d, kernel + ".s")
+                compile_isa(path, source)
+                reports.append((kernel, audit(path, kernel)))
     rc = 0
-    if len(rep) < 3:
-        print("expected three instantiations of k_lex_wave, found", len(rep))
-        rc = 1
-    for k, nd, bad in rep:
-        print("k_lex_wave instantiation %d: %d destination registers of hand-counted loads, %d suspicious uses" % (k, nd, len(bad)))
-        for t in bad[:8]:
-            print("    " + t)
-        if bad or nd == 0:
+    for kernel, rep in reports:
+        if len(rep) < 3:
+            print("expected three instantiations of %s, found %d" % (kernel, len(rep)))
             rc = 1
+        for k, nd, bad in rep:
+            print("%s instantiation %d: %d destination registers of hand-counted loads, %d suspicious uses" % (kernel, k, nd, len(bad)))
+            for t in bad[:8]:
+                print("    " + t)
+            if bad or nd == 0:
+                rc = 1
     return rc
 
 

@@ -1,5 +1,6 @@
 """Lexicographic Gauss-Seidel / SOR cycles and single sweeps: the wave pipeline (kernels_lexwave.hip) against the
-one-workgroup kernel (MGCMT_OPT_LEX_WAVE = 0).  Prints one JSON line per grid."""
+one-workgroup kernel (MGCMT_OPT_LEX_WAVE = 0); "band" = the row-band wavefront (kernels_lexband.hip, option value 2),
+"wave" = the skewed column blocks with a scan per row (option value 1).  Prints one JSON line per grid."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,13 +18,13 @@ def timed(p, fn, n):
 
 for g in (512, 1024, 4096, 16384):
     row = {"grid": g}
-    for wave in (1, 0):
+    for wave in (2, 1, 0):
         if wave == 0 and g > 4096:
             continue
         p = Plan(laplacian_operator(g, "2d") * (-1 / np.pi ** 2), 8, nvec=1)
         p.set_option(_lib.OPT_LEX_WAVE, wave)
         p.set_shifts([0.0]); p.fill(0, _lib.SLOT_F, 0, 1.0); p.fill(0, _lib.SLOT_V, 0, 0.0)
-        tag = "wave" if wave else "one_wg"
+        tag = {2: "band", 1: "wave", 0: "one_wg"}[wave]
         n = 5 if wave else 2
         row["gs_sweep_ms_" + tag] = timed(p, lambda: p.smooth(0, _lib.GS_LEX, 1, 1.0), n)
         row["gs_V22_ms_" + tag] = timed(p, lambda: p.vcycle(2, 2, _lib.GS_LEX, omega=1.0, nu_coarse=2), n)
@@ -33,4 +34,5 @@ for g in (512, 1024, 4096, 16384):
         p.close()
     if "gs_V22_ms_one_wg" in row:
         row["speedup_V22"] = round(row["gs_V22_ms_one_wg"] / row["gs_V22_ms_wave"], 1)
+        row["speedup_V22_band"] = round(row["gs_V22_ms_one_wg"] / row["gs_V22_ms_band"], 1)
     print(json.dumps(row), flush=True)

@@ -33,7 +33,7 @@ def test_lex_wave_sweeps_match_oracle(backend, g, level, kind, omega):
     v0, f = rng.rand(k, gl * gl), rng.rand(k, gl * gl)
     shifts = [0.0, 0.8]
     outs = {}
-    for wave in (1, 0):
+    for wave in (2, 1, 0):
         p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=k)
         p.set_option(_lib.OPT_LEX_WAVE, wave)
         p.set_shifts(shifts)
@@ -47,17 +47,20 @@ def test_lex_wave_sweeps_match_oracle(backend, g, level, kind, omega):
     okind = st.GS_LEX if kind == _lib.GS_LEX else st.SOR_LEX
     for q in range(k):
         want = st.smooth(X, Y, shifts[q], okind, v0[q], f[q], nu, omega)
-        assert rel_err(outs[1][q], want) < 1e-12, (q, "wave pipeline vs oracle")
+        assert rel_err(outs[2][q], want) < 1e-12, (q, "band wavefront vs oracle")
+        assert rel_err(outs[1][q], want) < 1e-12, (q, "scan pipeline vs oracle")
         assert rel_err(outs[0][q], want) < 1e-12, (q, "one-workgroup kernel vs oracle")
 
 
+@pytest.mark.parametrize("pipeline", [2, 1])
 @pytest.mark.parametrize("kind,okind,omega", [(_lib.GS_LEX, st.GS_LEX, 1.0), (_lib.SOR_LEX, st.SOR_LEX, 1.2)])
-def test_lex_wave_vcycle_matches_oracle(backend, kind, okind, omega):
+def test_lex_wave_vcycle_matches_oracle(backend, kind, okind, omega, pipeline):
     """Whole V-cycles with the reference's default smoother (ThesisProblem.py:101 passes smoother=solver.gseidel):
     the levels of at least 128 columns take the wave pipeline, the ones below it the one-workgroup kernel."""
     g = 512
     f = np.random.RandomState(3).rand(g * g)
     p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
+    p.set_option(_lib.OPT_LEX_WAVE, pipeline)
     p.set_shifts([0.4])
     p.upload(0, _lib.SLOT_F, 0, f)
     p.fill(0, _lib.SLOT_V, 0, 0.0)
@@ -73,13 +76,15 @@ def test_lex_wave_vcycle_matches_oracle(backend, kind, okind, omega):
 
 
 @pytest.mark.gpu
-def test_lex_wave_4096_cycle_against_oracle(hip_only):
+@pytest.mark.parametrize("pipeline", [2, 1])
+def test_lex_wave_4096_cycle_against_oracle(hip_only, pipeline):
     """The reference's default Gauss-Seidel at BASELINE config 2's grid: one V(2,2) cycle, every level through the
     wave pipeline down to 128^2 (several hundred waves in flight, hand-offs under load)."""
     g = 4096
     st.lib().mgo_set_threads(16)
     f = np.random.RandomState(8).rand(g * g)
     p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
+    p.set_option(_lib.OPT_LEX_WAVE, pipeline)
     p.set_shifts([0.0])
     p.upload(0, _lib.SLOT_F, 0, f)
     p.fill(0, _lib.SLOT_V, 0, 0.0)
