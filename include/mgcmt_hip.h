@@ -260,7 +260,7 @@ typedef enum mgcmt_option {
   MGCMT_OPT_RECOMPUTE = 3,  /* default 1: on levels of >= 2^22 points down-leg passes do not store the pre-smoothed iterate and
                                up-leg passes recompute it; 2: on every fused level; 0: never */
   MGCMT_OPT_GRAPH = 2,      /* default 1: mgcmt_vcycle replays its launch sequence as a HIP graph from the second call on */
-  MGCMT_OPT_LEX_WAVE = 5,   /* lexicographic Gauss-Seidel / SOR sweeps of constant-coefficient 2-D levels of >= 128 columns run as a
+  MGCMT_OPT_LEX_WAVE = 5,   /* lexicographic Gauss-Seidel / SOR sweeps of constant-coefficient 2-D levels of >= 16 x 16 points run as a
                                pipeline of waves over the whole chip: 2 = bands of 63 rows swept as a wavefront
                                (kernels_lexband.hip), 1 = skewed blocks of 64 columns with a scan per row (kernels_lexwave.hip);
                                0: one workgroup per vector everywhere */

@@ -85,9 +85,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   const double kF = beta * inv_int, kO = alpha, kE = -wU * cE_int * inv_int, kS = -wU * cS_int * inv_int, kN = -wL * cN_int * inv_int;
   const double kSW = -wU * cSW * inv_int, kSE = -wU * cSE * inv_int, kNW = -wL * cNW * inv_int, kNE = -wL * cNE * inv_int;
   // ... and for the lane on a 9-point level's last column (its centre-column coefficients and diagonal differ)
-  const double kFc = beta * inv_col, kOc = alpha * d_col * inv_col, kEc = -wU * cE_int * inv_col, kSc = -wU * cS_col * inv_col,
-               kNc = -wL * cN_col * inv_col, kSWc = -wU * cSW * inv_col, kSEc = -wU * cSE * inv_col, kNWc = -wL * cNW * inv_col,
-               kNEc = -wL * cNE * inv_col;
+  const double kOc = alpha * d_col * inv_col, kSc = -wU * cS_col * inv_col, kNc = -wL * cN_col * inv_col;
   const double q0 = -wL * cW_int * inv_int;
   const double q2 = q0 * q0, q4 = q2 * q2, q8 = q4 * q4;
   double qpow = q0, Q15 = 0.0, Q31 = 0.0;  // q0^(lane + 1); q0^((lane & 15) + 1) on the second 16 of every 32; q0^(lane - 31) on the upper 32
@@ -100,19 +98,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       if (m == lane + 1) qpow = acc;
     }
   }
-  // the last column's multipliers: its own q times one power of q0 less
-  const double qcol = -wL * cW_int * inv_col;
-  const double qc1 = qcol, qc2 = qcol * q0, qc4 = qcol * q0 * q2, qc8 = qcol * q0 * q2 * q4;
-  double qpowc = qcol, Q15c = 0.0, Q31c = 0.0;
-  {
-    double acc = qcol;  // qcol * q0^(m - 1)
-    for (int m = 1; m <= 64; ++m) {
-      if ((lane & 16) && m == (lane & 15) + 1) Q15c = acc;
-      if (lane >= 32 && m == lane - 31) Q31c = acc;
-      if (m == lane + 1) qpowc = acc;
-      acc *= q0;
-    }
-  }
+  const double qcol = -wL * cW_int * inv_col;  // the last column's own q
 
   // Old values come in three streams per row r, all read at this lane's column jr = J*64 + lane - r of that row:
   //   W[r] = v[r][jr]   S[r] = v[r][jr + 1]   S2[r] = v[r][jr + 2]     and  F[r] = f[r][jr].
@@ -144,46 +130,54 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     Rv[d] = 0;
   }
   const u64* rec_src = J > 0 ? left_rec : my_rec;  // (block 0 has no left neighbour: any valid address, result unused)
-  // issue the loads of row r's old values into slot SL: addresses clamped into the row, masks applied when the row is used.
+  // issue the loads of the next row's old values into slot SL (rows are asked for in order: i0, i0 + 1, ...).  The
+  // addresses are NOT clamped into the row: a window that crosses the grid's edge reads the end of the previous row or the
+  // start of the next one (the vectors carry MGCMT_HALO_ROWS rows of halo on either side), and whatever it finds there is
+  // masked when the row is used.  So the address is a wave-uniform running pointer — row min(r, nr) (row nr: the zero halo
+  // row), column J*64 - r — plus the lane's fixed offset: no vector arithmetic at all.
   // PLAIN: compiler-visible loads (the prologue, which the compiler may schedule and wait for as it likes); otherwise the
   // hand-counted asm loads of the row loop
-  const int lane8 = lane * 8, hi8 = (nc - 1) * 8;
-  auto issue_old = [&](auto plain, auto slot, int r) __attribute__((always_inline)) {
+  const unsigned lane8 = (unsigned)lane * 8u;
+  const long row_stride = ((long)nc - 1) * 8;  // one row down, one column left
+  int ld_r = i0;
+  const char* ldv = reinterpret_cast<const char*>(v + (long)i0 * nc + (J * 64 - i0));
+  const char* ldf = reinterpret_cast<const char*>(f + (long)i0 * nc + (J * 64 - i0));
+  auto issue_old = [&](auto plain, auto slot) __attribute__((always_inline)) {
     constexpr int SL = decltype(slot)::value;
-    const int rr = r < nr ? r : nr;
-    const double* row = v + (long)rr * nc;
-    const double* frow = f + (long)rr * nc;
-    const int jw8 = (J * 64 - r) * 8 + lane8;  // byte offset of this lane's column on that row
-    const unsigned o0 = (unsigned)clamp0(jw8, hi8), o1 = (unsigned)clamp0(jw8 + 8, hi8), o2 = (unsigned)clamp0(jw8 + 16, hi8);
     double &w_ = Wv[SL], &s_ = Sv[SL], &s2_ = S2v[SL], &f_ = Fv[SL];  // (named here: a variable that only an asm
-                                                                       //  statement mentions is not captured)
+    const char *pv = ldv, *pf = ldf;                                   //  statement mentions is not captured)
+    const unsigned off = lane8;
     if (decltype(plain)::value) {
-      if (USE_W) w_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + o0);
-      s_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + o1);
-      if (USE_S2) s2_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + o2);
-      f_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(frow) + o0);
-      return;
+      if (USE_W) w_ = *reinterpret_cast<const double*>(pv + off);
+      s_ = *reinterpret_cast<const double*>(pv + off + 8);
+      if (USE_S2) s2_ = *reinterpret_cast<const double*>(pv + off + 16);
+      f_ = *reinterpret_cast<const double*>(pf + off);
+    } else {
+      if (USE_W) MGCMT_LEX_LOAD_AT(w_, off, pv, 0);
+      MGCMT_LEX_LOAD_AT(s_, off, pv, 8);
+      if (USE_S2) MGCMT_LEX_LOAD_AT(s2_, off, pv, 16);
+      MGCMT_LEX_LOAD_AT(f_, off, pf, 0);
     }
-    // ONE straight-line sequence of loads: two alternatives (an unclamped fast form beside this one) meet in a phi, and
-    // the copies that phi costs read registers whose loads are still in flight — and free them for reuse as addresses
-    if (USE_W) MGCMT_LEX_LOAD_AT(w_, o0, row, 0);
-    MGCMT_LEX_LOAD_AT(s_, o1, row, 0);
-    if (USE_S2) MGCMT_LEX_LOAD_AT(s2_, o2, row, 0);
-    MGCMT_LEX_LOAD_AT(f_, o0, frow, 0);
+    const long step = ld_r < nr ? row_stride : 0;  // (rows nr + 1 .. are never used: the pointer rests on row nr)
+    ldv += step;
+    ldf += step;
+    ++ld_r;
   };
-  // ... and of row r's edge record (lanes 0..3 matter; every lane loads)
+  // ... and of the next row's edge record (lanes 0..3 matter; every lane loads).  Rows behind the left block's last one
+  // read into the next block's records (inside the buffer; never used)
   const unsigned roff = (unsigned)(lane & 3) * 8u;
-  auto issue_rec = [&](auto plain, auto slot, int r) __attribute__((always_inline)) {
+  const u64* ldr = rec_src + (long)i0 * 4;
+  auto issue_rec = [&](auto plain, auto slot) __attribute__((always_inline)) {
     constexpr int SL = decltype(slot)::value;
     u64& r_ = Rv[SL];
-    const int rc = r > nr - 1 ? nr - 1 : r;
-    const u64* rbase = rec_src + (long)rc * 4;
+    const u64* rbase = ldr;
     if (decltype(plain)::value) {
       r_ = load_granule(rbase + (lane & 3));
-      return;
+    } else {
+      const unsigned ro = roff;  // (a use outside the asm statement: see above)
+      MGCMT_LEX_LOAD_AT_SC1(r_, ro, rbase);
     }
-    const unsigned ro = roff;  // (a use outside the asm statement: see above)
-    MGCMT_LEX_LOAD_AT_SC1(r_, ro, rbase);
+    ldr += 4;
   };
 
   // edge records of the left block: the four granules of a row are read by lanes 0..3 (every lane loads, the address is
@@ -198,16 +192,15 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   const u64 dbg_t0 = now_ticks();
 #endif
   auto unpack = [&](u64 R, double& c1, double& c2) __attribute__((always_inline)) {  // false: the record is not complete yet
-    const u64 g2 = lane_bits(R, 2), g3 = lane_bits(R, 3);
-    c1 = __builtin_bit_cast(double, (g2 & 0xffffffffull) | (g3 << 32));  // the left block's lane 63
-    u64 tags = g2 & g3;
+    const unsigned lo = (unsigned)R, hi = (unsigned)(R >> 32);  // (the register's two halves: half a double, the tag)
+    c1 = __builtin_bit_cast(double, (u64)lane_word(lo, 2) | ((u64)lane_word(lo, 3) << 32));  // the left block's lane 63
+    unsigned tags = lane_word(hi, 2) & lane_word(hi, 3);
     c2 = 0.0;
     if (!FIVE) {
-      const u64 g0 = lane_bits(R, 0), g1 = lane_bits(R, 1);
-      c2 = __builtin_bit_cast(double, (g0 & 0xffffffffull) | (g1 << 32));  // ... lane 62
-      tags &= g0 & g1;
+      c2 = __builtin_bit_cast(double, (u64)lane_word(lo, 0) | ((u64)lane_word(lo, 1) << 32));  // ... lane 62
+      tags &= lane_word(hi, 0) & lane_word(hi, 1);
     }
-    return (tags >> 32) == 1ull;
+    return tags == 1u;
   };
   auto wait_record = [&](int row, double& c1, double& c2) __attribute__((always_inline)) {  // the slow path: ask until the record is complete
 #ifdef MGCMT_LEXWAVE_DEBUG
@@ -234,8 +227,8 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
 
   // fill the pipeline: old values of rows i0 .. i0 + kDepth, records of rows i0 .. i0 + kRec - 1, with loads the compiler sees (it waits for them before the row loop's
   // first asm statement reads their registers; from then on nothing but the loop's own asm touches a slot)
-  for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) { issue_old(Checked<true>{}, sl, i0 + decltype(sl)::value); });
-  for_slots<kRec>([&](auto sl) __attribute__((always_inline)) { issue_rec(Checked<true>{}, sl, i0 + decltype(sl)::value); });
+  for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) { issue_old(Checked<true>{}, sl); });
+  for_slots<kRec>([&](auto sl) __attribute__((always_inline)) { issue_rec(Checked<true>{}, sl); });
   drain_loads();
   // The compiler does not know that the drain above completed its loads.  Left at that, it carries "slot k's load may be
   // pending" around the loop and puts its own s_waitcnt vmcnt(3 (kSlots - 1 - k)) before the first read of slot k in EVERY
@@ -250,53 +243,58 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     settle(Rv[d]);
   }
 
+  // rows on which every lane and everything its stencil reaches lies inside the grid: jmin >= 1 and jmin + 64 <= nc - 1 (- 2)
+  // (rows int_lo .. int_lo + int_span; a 9-point level's last row takes the general form; an empty range matches nothing)
+  const int int_lo = J * 64 + 64 - nc + (FIVE ? 1 : 2);
+  const int int_hi = J * 64 - 1 < (FIVE ? nr - 1 : nr - 2) ? J * 64 - 1 : (FIVE ? nr - 1 : nr - 2);
+  const unsigned int_span = int_hi >= int_lo ? (unsigned)(int_hi - int_lo) : 0u;
+  const int int_lo_eff = int_hi >= int_lo ? int_lo : (1 << 30);
+  const double lane0 = lane == 0 ? 1.0 : 0.0;
+  // running addresses of the row's stores: the window's first column on row i; the row's record (as seen from lane 60)
+  char* vst = reinterpret_cast<char*>(v + (long)i0 * nc + (J * 64 - i0));
+  char* rst = reinterpret_cast<char*>(my_rec + (long)i0 * 4 - 60);
   double prev = 0.0;            // new values of the previous row (this lane's column + 1 there)
   double c1p = 0.0, c2p = 0.0;  // the left block's edge values on the previous row
   if (J > 0 && i0 - 1 >= 0 && i0 - 1 <= left_last) wait_record(i0 - 1, c1p, c2p);
 
-  // one row; FAST: every lane is an interior point on this row and the rows being prefetched need no clamping.  PH = the
-  // pipelines' phase, (i - i0) mod (kDepth + 1): the registers of row i are slot PH, those of row i + 1 slot PH + 1, and
-  // the row fetched now takes slot PH over — a ROTATING register file: a value that is still in flight is never moved
-  // (a register copy would make the wave wait for its load)
-  auto row_step = [&](auto ph, int i) __attribute__((always_inline)) {
+  // One row.  PH = the pipelines' phase, (i - i0) mod kSlots: the registers of row i are slot PH, those of row i + 1 slot
+  // PH + 1, and the row fetched now takes slot PH over — a ROTATING register file: a value that is still in flight is never
+  // moved (a register copy would read a register whose load has not landed).
+  //
+  // Forms of the row, chosen by wave-uniform tests:
+  //   interior   every lane and everything its stencil reaches lies inside the grid: no masks, no tests;
+  //   edge       the window crosses the grid's left or right edge (or, 9-point, holds its last column);
+  //   general    the last row of a 9-point level (own-row coefficients differ): the scan over (p, q) pairs.
+  // The EDGE rows are the sweep's critical path: with T(J, i) = max(T(J - 1, i), T(J, i - 1)) + t(J, i) every monotone path
+  // through the (block, row) lattice has the same number of steps, and the diagonal on which each block holds column 0
+  // (and the one on which it holds the last column) consists of edge rows only.  So the edge form carries only the masks
+  // it cannot do without:
+  //   - lanes left of the grid must contribute nothing to the lanes right of them: p = 0 there (their x is then 0 by
+  //     itself: the scan has nothing to carry and no block works on that row further left);
+  //   - the lanes on columns 0 and nc - 1 must not see what lies beyond: SW (9-point) resp. E, SE are masked, and NE —
+  //     the lane's own value of the previous row — by zeroing x right of the grid (9-point only; the 5-point operator
+  //     never reads a value right of the grid that the masks do not cover: garbage there stays there);
+  //   - the last column of a 9-point level (its own diagonal and N / S coefficients, its own q) is patched AFTER the
+  //     regular scan: x_lc = pc + qcol x_(lc - 1) with pc from p by the ratio of the two diagonals.
+  const double rho = inv_col * d_int;  // (k..c = rho k.. for every term whose coefficient the last column shares)
+  const double dS = kSc - rho * kS, dN = kNc - rho * kN, dO = kOc - rho * kO;
+  auto row_body = [&](auto ph, auto interior, int i, double& x, double& c1, double& c2) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph)::value, NEXT = (PH + 1) % kSlots;
-    const int jmin = J * 64 - i;  // lane 0's column
-    // Three forms of the row, chosen by wave-uniform tests:
-    //   interior   every lane and everything its stencil reaches lies inside the grid: no masks at all;
-    //   edge       the window crosses the grid's left or right edge (or, 9-point, holds its last column): the old values
-    //              outside the grid are masked to zero, lanes outside produce p = 0 and x = 0 — which is all the left edge
-    //              needs: a lane outside contributes nothing to the lanes right of it whatever the scan multiplies it with,
-    //              and the left block's edge value there is an outside lane's 0; the last column (9-point Galerkin levels:
-    //              its own diagonal, N and S coefficients) takes its own constants and its own scan multipliers;
-    //   general    the last row of a 9-point level (own-row coefficients differ): the scan over (p, q) pairs.
-    // The edge rows are the sweep's critical path — row i becomes available to every block only after the block that
-    // holds column 0 on it has finished it — so they must not be slower than the interior rows.
-    const bool INTERIOR = jmin >= 1 && jmin + 64 <= nc - (FIVE ? 1 : 2);
-    const bool FAST = FIVE || i < nr - 1;  // (every row but a 9-point level's last one)
-    // the record of row i — and everything issued before it: the old values of rows i and i + 1 — has landed when at most
-    // what was issued after it is in flight
-    wait_loads<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH]);
-    double own = Wv[PH], e = Sv[PH], fv = Fv[PH];
-    double sw = Wv[NEXT], s = Sv[NEXT], se = S2v[NEXT];
+    constexpr bool IN = decltype(interior)::value;
+    // (the slots are only ever read here: a masked value is a new value — a slot that one form of the row changed and the
+    // other did not would meet itself in a phi, and the copies that costs read registers whose loads are in flight)
+    const double &own = Wv[PH], &e = Sv[PH], &fv = Fv[PH];
+    const double &sw = Wv[NEXT], &s = Sv[NEXT], &se = S2v[NEXT];
     const u64 rq_now = Rv[PH];
-    const int j = jmin + lane;
-    bool valid = true;
-    if (!INTERIOR) {  // columns outside the grid read as zero (the addresses were clamped)
-      valid = j >= 0 && j < nc;
-      const bool right = j + 1 >= 0 && j + 1 < nc, left = j - 1 >= 0 && j - 1 < nc;
-      if (!valid) own = 0.0, fv = 0.0, s = 0.0;
-      if (!right) e = 0.0, se = 0.0;
-      if (!left) sw = 0.0;
-    }
     // new values of row i-1: NE = this lane, N = lane - 1, NW = lane - 2 (the left block's edge beyond lane 0)
-    const double n = from_left(prev, lane) + (lane == 0 ? c1p : 0.0);
+    const double n = fma(c1p, lane0, from_left(prev, lane));
     const double ne = prev;
     double nw = 0.0;
-    if (!FIVE) nw = from_left(n, lane) + (lane == 0 ? c2p : 0.0);
-
-    double p, qmul;  // x = p + qmul * (value left of lane 0)
-    if (FAST) {
-      p = kF * fv;
+    if (!FIVE) nw = fma(c2p, lane0, from_left(n, lane));
+    c1 = 0.0;
+    c2 = 0.0;
+    if (IN) {
+      double p = kF * fv;
       if (OWN) p = fma(kO, own, p);
       p = fma(kE, e, p);
       p = fma(kS, s, p);
@@ -307,41 +305,40 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
         p = fma(kNW, nw, p);
         p = fma(kNE, ne, p);
       }
-      const bool has_last_col = !FIVE && jmin <= nc - 1 && jmin + 63 >= nc - 1;  // (wave-uniform)
-      if (has_last_col) {
-        // the lane on the last column: its own diagonal and N / S coefficients, and q = -wL cW / d_col in its multipliers
-        const bool lc = j == nc - 1;
-        double pc = kFc * fv;
-        pc = fma(kOc, own, pc);
-        pc = fma(kEc, e, pc);
-        pc = fma(kSc, s, pc);
-        pc = fma(kNc, n, pc);
-        pc = fma(kSWc, sw, pc);
-        pc = fma(kSEc, se, pc);
-        pc = fma(kNWc, nw, pc);
-        pc = fma(kNEc, ne, pc);
-        // (assignments under `if`, not `?:` between captured constants: see the note in the general form below)
-        double m1 = q0, m2 = q2, m4 = q4, m8 = q8, m15 = Q15, m31 = Q31;
-        qmul = qpow;
-        if (lc) {
-          p = pc;
-          m1 = qc1;
-          m2 = qc2;
-          m4 = qc4;
-          m8 = qc8;
-          m15 = Q15c;
-          m31 = Q31c;
-          qmul = qpowc;
+      p = fma(q0, row_shr<1>(p, lane), p);
+      p = fma(q2, row_shr<2>(p, lane), p);
+      p = fma(q4, row_shr<4>(p, lane), p);
+      p = fma(q8, row_shr<8>(p, lane), p);
+      p = fma(Q15, bcast15(p, lane), p);
+      p = fma(Q31, bcast31(p, lane), p);
+      // (an interior row has columns left of its window: the left block works on it)
+      if (!unpack(rq_now, c1, c2)) wait_record(i, c1, c2);
+      x = fma(qpow, c1, p);
+      *reinterpret_cast<double*>(vst + lane8) = x;
+    } else {
+      const int j = J * 64 - i + lane;
+      const bool valid = (unsigned)j < (unsigned)nc;
+      const bool FAST = FIVE || i < nr - 1;  // (every row but a 9-point level's last one)
+      double p, qmul;                        // x = p + qmul * (value left of lane 0)
+      if (FAST) {
+        const bool right = j < nc - 1;
+        const double em = right ? e : 0.0;
+        p = kF * fv;
+        if (OWN) p = fma(kO, own, p);
+        p = fma(kE, em, p);
+        p = fma(kS, s, p);
+        p = fma(kN, n, p);
+        if (!FIVE) {
+          const double sem = right ? se : 0.0, swm = j < 1 ? 0.0 : sw;
+          p = fma(kSW, swm, p);
+          p = fma(kSE, sem, p);
+          p = fma(kNW, nw, p);
+          p = fma(kNE, ne, p);
         }
+        double pc = 0.0;
+        const bool has_last_col = !FIVE && J * 64 - i <= nc - 1 && J * 64 - i + 63 >= nc - 1;  // (wave-uniform)
+        if (has_last_col) pc = fma(dO, own, fma(dN, n, fma(dS, s, rho * p)));
         if (!valid) p = 0.0;
-        p = fma(m1, row_shr<1>(p, lane), p);
-        p = fma(m2, row_shr<2>(p, lane), p);
-        p = fma(m4, row_shr<4>(p, lane), p);
-        p = fma(m8, row_shr<8>(p, lane), p);
-        p = fma(m15, bcast15(p, lane), p);
-        p = fma(m31, bcast31(p, lane), p);
-      } else {
-        if (!INTERIOR && !valid) p = 0.0;
         p = fma(q0, row_shr<1>(p, lane), p);
         p = fma(q2, row_shr<2>(p, lane), p);
         p = fma(q4, row_shr<4>(p, lane), p);
@@ -349,39 +346,51 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
         p = fma(Q15, bcast15(p, lane), p);
         p = fma(Q31, bcast31(p, lane), p);
         qmul = qpow;
-      }
-    } else {
-      const bool last_col = !FIVE && j == nc - 1, last_row = !FIVE && i == nr - 1;
-      // the centre-column / own-row coefficients change on the last column / row (Galerkin levels)
-      // (assignments under `if`, not `?:` between the captured constants: a select of two captured variables keeps the
-      // whole closure in scratch memory)
-      double cN = cN_int, cS = cS_int, cW = cW_int, cE = cE_int, d = d_int, invd = inv_int;
-      if (last_col) {
-        cN = cN_col;
-        cS = cS_col;
-        d = d_col;
-        invd = inv_col;
-      }
-      if (last_row) {
-        cW = cW_row;
-        cE = cE_row;
-        d = d_row;
-        invd = inv_row;
-        if (last_col) {
-          d = d_cor;
-          invd = inv_cor;
+        if (i <= left_last) {  // (block 0: left_last = -1)
+          if (!unpack(rq_now, c1, c2)) wait_record(i, c1, c2);
         }
-      }
-      const double lower = fma(cNW, nw, fma(cN, n, cNE * ne));
-      const double upper = fma(cE, e, fma(cSW, sw, fma(cS, s, cSE * se)));
-      p = (alpha * d * own + beta * fv - wU * upper - wL * lower) * invd;
-      double qq = -wL * cW * invd;
-      if (!valid) {
-        p = 0.0;
-        qq = 0.0;
-      }
-      // inclusive scan of the maps x -> p + q x over the lanes (`first` applied before `second`:
-      // p = second.p + second.q * first.p, q = second.q * first.q)
+        x = fma(qmul, c1, p);
+        if (has_last_col) {
+          const double xl = fma(c1, lane0, from_left(x, lane));
+          const double xc = fma(qcol, xl, pc);
+          if (j == nc - 1) x = xc;
+        }
+      } else {
+        // the general form: every value outside the grid reads as zero
+        const bool right = j + 1 >= 0 && j + 1 < nc, left = j - 1 >= 0 && j - 1 < nc;
+        const double ownm = valid ? own : 0.0, fvm = valid ? fv : 0.0, sm = valid ? s : 0.0;
+        const double em = right ? e : 0.0, sem = right ? se : 0.0, swm = left ? sw : 0.0;
+        const bool last_col = !FIVE && j == nc - 1, last_row = !FIVE && i == nr - 1;
+        // the centre-column / own-row coefficients change on the last column / row (Galerkin levels)
+        // (assignments under `if`, not `?:` between the captured constants: a select of two captured variables keeps the
+        // whole closure in scratch memory)
+        double cN = cN_int, cS = cS_int, cW = cW_int, cE = cE_int, d = d_int, invd = inv_int;
+        if (last_col) {
+          cN = cN_col;
+          cS = cS_col;
+          d = d_col;
+          invd = inv_col;
+        }
+        if (last_row) {
+          cW = cW_row;
+          cE = cE_row;
+          d = d_row;
+          invd = inv_row;
+          if (last_col) {
+            d = d_cor;
+            invd = inv_cor;
+          }
+        }
+        const double lower = fma(cNW, nw, fma(cN, n, cNE * ne));
+        const double upper = fma(cE, em, fma(cSW, swm, fma(cS, sm, cSE * sem)));
+        p = (alpha * d * ownm + beta * fvm - wU * upper - wL * lower) * invd;
+        double qq = -wL * cW * invd;
+        if (!valid) {
+          p = 0.0;
+          qq = 0.0;
+        }
+        // inclusive scan of the maps x -> p + q x over the lanes (`first` applied before `second`:
+        // p = second.p + second.q * first.p, q = second.q * first.q)
 #define MGCMT_LEX_STEP(FETCH, COND)             \
   {                                             \
     const double pp = FETCH(p, lane);           \
@@ -391,33 +400,42 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       qq = qq * pq;                             \
     }                                           \
   }
-      MGCMT_LEX_STEP(row_shr<1>, (lane & 15) >= 1)
-      MGCMT_LEX_STEP(row_shr<2>, (lane & 15) >= 2)
-      MGCMT_LEX_STEP(row_shr<4>, (lane & 15) >= 4)
-      MGCMT_LEX_STEP(row_shr<8>, (lane & 15) >= 8)
-      MGCMT_LEX_STEP(bcast15, (lane & 16) != 0)
-      MGCMT_LEX_STEP(bcast31, lane >= 32)
+        MGCMT_LEX_STEP(row_shr<1>, (lane & 15) >= 1)
+        MGCMT_LEX_STEP(row_shr<2>, (lane & 15) >= 2)
+        MGCMT_LEX_STEP(row_shr<4>, (lane & 15) >= 4)
+        MGCMT_LEX_STEP(row_shr<8>, (lane & 15) >= 8)
+        MGCMT_LEX_STEP(bcast15, (lane & 16) != 0)
+        MGCMT_LEX_STEP(bcast31, lane >= 32)
 #undef MGCMT_LEX_STEP
-      qmul = qq;
+        qmul = qq;
+        if (i <= left_last) {
+          if (!unpack(rq_now, c1, c2)) wait_record(i, c1, c2);
+        }
+        x = fma(qmul, c1, p);
+      }
+      if (!FIVE && !valid) x = 0.0;
+      if (valid) *reinterpret_cast<double*>(vst + lane8) = x;
     }
-    // the value left of lane 0 on this row: the left block's lane 63 (its record came with the row's old values)
-    double c1 = 0.0, c2 = 0.0;
-    if (J > 0 && i <= left_last) {
-      if (!unpack(rq_now, c1, c2)) wait_record(i, c1, c2);
-    }
-    double x = fma(qmul, c1, p);
-    if (!valid) x = 0.0;
-    // (wave-uniform row base + 32-bit lane offset: one scalar add per row, no 64-bit lane arithmetic)
-    if (valid) *reinterpret_cast<double*>(reinterpret_cast<char*>(v + (long)i * nc + jmin) + (unsigned)lane8) = x;
     {  // the row's edge record: {tag, half a double} granules, ONE store instruction (lanes 60..63; FIVE: 62, 63)
       const double t1 = from_right(x, lane);   // lane 62: x63, lane 61: x62
       const double t2 = from_right(t1, lane);  // lane 60: x62
       const double src = lane == 63 ? x : (lane == 60 ? t2 : t1);
       const u64 bits = __builtin_bit_cast(u64, src);
       const u64 word = (1ull << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xffffffffull));
-      if (lane >= (FIVE ? 62 : 60))
-        store_granule(reinterpret_cast<u64*>(reinterpret_cast<char*>(my_rec + (long)i * 4 - 60) + (unsigned)lane8), word);
+      if (lane >= (FIVE ? 62 : 60)) store_granule(reinterpret_cast<u64*>(rst + lane8), word);
     }
+  };
+  auto row_step = [&](auto ph, int i) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph)::value, NEXT = (PH + 1) % kSlots;
+    const bool INTERIOR = (unsigned)(i - int_lo_eff) <= int_span;
+    // the record of row i — and everything issued before it: the old values of rows i and i + 1 — has landed when at most
+    // what was issued after it is in flight
+    wait_loads<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH]);
+    double x, c1, c2;
+    if (INTERIOR) row_body(ph, Checked<true>{}, i, x, c1, c2);
+    else row_body(ph, Checked<false>{}, i, x, c1, c2);
+    vst += row_stride;
+    rst += 32;
     prev = x;
     c1p = c1;
     c2p = c2;
@@ -425,8 +443,8 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     // loads land in the very registers the slot had (issued earlier, the old and the new value would be alive together, the
     // slots would rotate through registers, and the copies that restore them at the loop's latch would read registers whose
     // loads are still in flight)
-    issue_rec(Checked<false>{}, Int<(PH + kRec) % kSlots>{}, i + kRec);
-    issue_old(Checked<false>{}, ph, i + kDepth + 1);
+    issue_rec(Checked<false>{}, Int<(PH + kRec) % kSlots>{});
+    issue_old(Checked<false>{}, ph);
   };
   // ONE loop over the block's rows, kSlots rows per trip with compile-time phases; the last trip skips the rows behind i1
   // (a skipped step issues nothing, and nothing behind it consumes)
@@ -450,7 +468,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
 }  // namespace
 
 bool lex_wave_supported(const KGrid& g, const KOp& op) {
-  return g.coarsen_rows && (op.five_point || op.nine_const) && g.nc >= 128 && g.nr >= 64 && g.nr + g.nc < (1L << 30);
+  return g.coarsen_rows && (op.five_point || op.nine_const) && g.nc >= 16 && g.nr >= 16 && g.nr + g.nc < (1L << 30);
 }
 
 long lex_wave_blocks(const KGrid& g) { return (g.nr + g.nc - 1 + 63) / 64; }

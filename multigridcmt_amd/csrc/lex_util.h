@@ -94,6 +94,7 @@ __device__ __forceinline__ u64 lane_bits(u64 u, int k) {
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), k);
   return ((u64)hi << 32) | lo;
 }
+__device__ __forceinline__ unsigned lane_word(unsigned x, int k) { return (unsigned)__builtin_amdgcn_readlane((int)x, k); }
 __device__ __forceinline__ u64 vote(bool x) { return __ballot(x); }
 __device__ __forceinline__ unsigned load_word(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_word(unsigned* p, unsigned x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -110,6 +111,7 @@ __device__ __forceinline__ double bcast31(double v, int) { return __shfl(v, 31);
 __device__ __forceinline__ double from_left(double v, int lane) { const double r = __shfl_up(v, 1); return lane >= 1 ? r : 0.0; }
 __device__ __forceinline__ double from_right(double v, int lane) { const double r = __shfl_down(v, 1); return lane <= 62 ? r : 0.0; }
 __device__ __forceinline__ u64 lane_bits(u64 u, int k) { return (u64)__shfl((long long)u, k); }
+__device__ __forceinline__ unsigned lane_word(unsigned x, int k) { return (unsigned)__shfl((int)x, k); }
 __device__ __forceinline__ u64 vote(bool x) {
   u64 m = 0;
   for (int k = 0; k < 64; ++k) m |= (u64)(__shfl(x ? 1 : 0, k) & 1) << k;

@@ -62,7 +62,7 @@ void launch_lex_sweep(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doub
                       double wU, double wL, int k);
 
 // the same sweep as a pipeline of waves over the whole chip (kernels_lexwave.hip; constant-coefficient operators on
-// grids of at least 128 columns).  carry: k * lex_wave_blocks(g) * g.nr * 4 eight-byte granules; sync: 2 words; sync[1]
+// grids of at least 16 x 16 points).  carry: k * lex_wave_blocks(g) * g.nr * 4 eight-byte granules; sync: 2 words; sync[1]
 // != 0 after the sweep: a block gave up waiting (reported by the next synchronising call)
 bool lex_wave_supported(const KGrid& g, const KOp& op);
 long lex_wave_blocks(const KGrid& g);

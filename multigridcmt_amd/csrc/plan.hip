@@ -282,7 +282,7 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
   if (p->use_lex_wave && p->levels[l].nr == p->levels[l].gr && lex_wave_supported(g, op)) {
     const bool band = p->use_lex_wave == 2;
     const size_t blocks = (size_t)lex_wave_blocks(g);
-    const size_t need_scan = (size_t)p->nvec * blocks * g.nr * 4, need_band = (size_t)p->nvec * lex_band_count(g) * lex_band_stride(g);
+    const size_t need_scan = (size_t)p->nvec * blocks * g.nr * 4 + 64 /* the record prefetch runs a few rows past the last block's */, need_band = (size_t)p->nvec * lex_band_count(g) * lex_band_stride(g);
     const size_t need_carry = band ? need_band : need_scan, need_sync = 2 + 4 * (size_t)p->nvec * blocks;  // (2 words used; the rest is the diagnostic build's per-block record)
     if (need_carry > p->lex_carry_doubles || need_sync > p->lex_sync_words) {
       MG_HIP(hipStreamSynchronize(s));

@@ -8,7 +8,9 @@ in the worst case, which is a memory fault on the GPU.  This script compiles the
 row loop (from its header on), that no destination of a hand-counted load is
   - the source of a plain v_mov_b32 (a copy),
   - the address operand of any global load / store,
-  - stored to scratch.
+  - stored to scratch,
+  - shared by two loads of the loop,
+and that the compiler put no partial vmcnt wait of its own into the loop.
 Exit status 0 = clean.  Usage: python scripts/audit_lexwave_isa.py [file.s [kernel name]]"""
 import os, re, subprocess, sys, tempfile
 
@@ -44,11 +46,18 @@ def audit(path, kernel="k_lex_wave"):
             continue
         loop = [l.strip() for l in body[headers[-1]:]]
         dests = set()
+        seen = {}
         for t in loop:
             m = re.search(r"global_load_dwordx2 v\[(\d+):(\d+)\], v\d+, s\[", t)
             if m:
                 dests.update({int(m.group(1)), int(m.group(2))})
+                seen[m.group(1)] = seen.get(m.group(1), 0) + 1
         bad = []
+        # every slot has registers of its own: a destination that two loads of the loop share is a temporary the slot is
+        # copied out of afterwards — while the load is in flight
+        for reg, count in seen.items():
+            if count > 1:
+                bad.append("v[%s:..] is the destination of %d hand-counted loads" % (reg, count))
         for t in loop:
             m = re.match(r"v_mov_b32\S*\s+v(\d+), v(\d+)", t)
             if m and int(m.group(2)) in dests and "dpp" not in t:

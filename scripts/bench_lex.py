@@ -27,6 +27,9 @@ for g in (512, 1024, 4096, 16384):
         tag = {2: "band", 1: "wave", 0: "one_wg"}[wave]
         n = 5 if wave else 2
         row["gs_sweep_ms_" + tag] = timed(p, lambda: p.smooth(0, _lib.GS_LEX, 1, 1.0), n)
+        if g >= 1024:   # the 9-point Galerkin level below the top (half the rows)
+            p.fill(1, _lib.SLOT_F, 0, 1.0); p.fill(1, _lib.SLOT_V, 0, 0.0)
+            row["gs_sweep9_ms_" + tag] = timed(p, lambda: p.smooth(1, _lib.GS_LEX, 1, 1.0), n)
         row["gs_V22_ms_" + tag] = timed(p, lambda: p.vcycle(2, 2, _lib.GS_LEX, omega=1.0, nu_coarse=2), n)
         row["gs_V44_ms_" + tag] = timed(p, lambda: p.vcycle(2, 2, _lib.GS_LEX, omega=1.0, nu_coarse=4), n)
         row["sor_V22_ms_" + tag] = timed(p, lambda: p.vcycle(2, 2, _lib.SOR_LEX, omega=1.3, nu_coarse=2), n)

@@ -22,7 +22,7 @@ def _galerkin_factors(g, levels):
     return np.ascontiguousarray(X), np.ascontiguousarray(Y)
 
 
-@pytest.mark.parametrize("g,level", [(128, 0), (256, 0), (256, 1), (512, 2)])
+@pytest.mark.parametrize("g,level", [(128, 0), (256, 0), (256, 1), (512, 2), (64, 0), (32, 0), (16, 0), (128, 1), (128, 2), (128, 3)])
 @pytest.mark.parametrize("kind,omega", [(_lib.GS_LEX, 1.0), (_lib.SOR_LEX, 1.3)])
 def test_lex_wave_sweeps_match_oracle(backend, g, level, kind, omega):
     """nu sweeps on level `level` of a plan on grid g (level > 0: the 9-point Galerkin operator with its modified last
@@ -56,7 +56,7 @@ def test_lex_wave_sweeps_match_oracle(backend, g, level, kind, omega):
 @pytest.mark.parametrize("kind,okind,omega", [(_lib.GS_LEX, st.GS_LEX, 1.0), (_lib.SOR_LEX, st.SOR_LEX, 1.2)])
 def test_lex_wave_vcycle_matches_oracle(backend, kind, okind, omega, pipeline):
     """Whole V-cycles with the reference's default smoother (ThesisProblem.py:101 passes smoother=solver.gseidel):
-    the levels of at least 128 columns take the wave pipeline, the ones below it the one-workgroup kernel."""
+    the levels of at least 16 x 16 points take the wave pipeline, the coarsest ones the one-workgroup kernel."""
     g = 512
     f = np.random.RandomState(3).rand(g * g)
     p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
