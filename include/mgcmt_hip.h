@@ -264,6 +264,8 @@ typedef enum mgcmt_option {
                                pipeline of waves over the whole chip: 2 = bands of 63 rows swept as a wavefront
                                (kernels_lexband.hip), 1 = skewed blocks of 64 columns with a scan per row (kernels_lexwave.hip);
                                0: one workgroup per vector everywhere */
+  MGCMT_OPT_LEX_CHAIN = 6,  /* default 1: the nu Gauss-Seidel sweeps of a smoothing step run chained in ONE launch of the scan pipeline
+                               (sweep s + 1 follows sweep s a few rows behind); 0: one launch per sweep.  Same arithmetic, same bits */
   MGCMT_OPT_TAIL = 4        /* default 1: the 2-D levels of at most 32 x 32 points below a cycle's top level, coarse solve
                                included, run as ONE launch out of LDS (needs MGCMT_OPT_FUSED; not with Gram-Schmidt) */
 } mgcmt_option;

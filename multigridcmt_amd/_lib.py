@@ -23,6 +23,7 @@ OPT_FUSED = 0
 OPT_FUSED_ROWS = 1
 OPT_TAIL = 4
 OPT_LEX_WAVE = 5
+OPT_LEX_CHAIN = 6
 OPT_GRAPH = 2
 OPT_RECOMPUTE = 3
 

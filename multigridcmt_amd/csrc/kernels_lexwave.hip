@@ -44,27 +44,50 @@ struct LexWaveArgs {
   double crow[3], ccol[3], ccorner;  // last row: own-row coefficients (W, C, E); last column: centre column (N, C, S)
   const double* shifts;
   double alpha, beta, wU, wL;
-  unsigned long long* carry;  // [vector][block][row][4] granules {tag = 1 : 32, half of a double : 32}: lanes 62 / 63's new values
+  unsigned long long* carry;  // [sweep][vector][block][row][4] granules {tag = 1 : 32, half of a double : 32}: lanes 62 / 63's new values
   unsigned* sync;             // [0] ticket, [1] error
   long carry_stride;          // granules per vector
+  int nsweeps;                // sweeps chained in this launch (1: the plain sweep)
+  int rec_rows;               // rows of a block's record array: nr + kTerminalRows
+  long sweep_stride;          // granules per sweep
 };
 
+// rows of "terminal" records a block of a chained sweep appends to its own: present = the block has finished and every
+// store of it has been acknowledged
+constexpr int kTerminalRows = 16;
+
 // FIVE: constant 5-point operator (no corner terms, no special last row / column); OWN: the sweep uses the point's own
-// old value (alpha != 0: the homogeneous SOR recurrence)
-template <bool FIVE, bool OWN>
+// old value (alpha != 0: the homogeneous SOR recurrence); CH: several sweeps chained in one launch.
+//
+// Chained sweeps (CH): sweep s runs behind sweep s - 1 on the same vector, in the same launch.  Block (s, J) may read the
+// old values of its rows i, i + 1 — sweep s - 1's results in its own window and the two columns right of it — once blocks J
+// and J + 1 of sweep s - 1 have finished row i + 1 AND their stores are visible.  Stores of v are write-through and loads
+// of v bypass the caches in these kernels; a block's record of row r is written after the wait at the top of step r, which
+// (memory operations complete in order) has seen the stores of rows <= r - kRec acknowledged.  So "record (R + kRec) of
+// block J + 1 of sweep s - 1 is there" says: that block's rows <= R are visible, and — it has consumed block J's record
+// of row R + kRec to get there — so are block J's.  Block (s, J) asks for that record before it issues the loads of row
+// R, kRec steps ahead like its own left neighbour's record, and spins (bounded) when it is not there yet.  Blocks get
+// their numbers in the order of (J + 2 s, s), so a block only ever waits for blocks that have started.
+template <bool FIVE, bool OWN, bool CH>
 __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   const int lane = threadIdx.x;
   // block number = order of arrival: whoever this block waits for has started before it
   unsigned ticket = 0;
   if (lane == 0) ticket = atomicAdd(&a.sync[0], 1u);
   ticket = (unsigned)uniform(__shfl((int)ticket, 0));
-  const int q = (int)(ticket / (unsigned)a.nblocks);
-  const int J = (int)(ticket % (unsigned)a.nblocks);
+  const int nsw = CH ? a.nsweeps : 1;
+  const int per_vector = CH ? (a.nblocks + 2 * (nsw - 1)) * nsw : a.nblocks;  // (chained: some numbers stand for no block)
+  const int q = (int)(ticket / (unsigned)per_vector);
+  const int tv = (int)(ticket % (unsigned)per_vector);
+  const int sw = CH ? tv % nsw : 0;                 // the sweep this block belongs to
+  const int J = CH ? tv / nsw - 2 * sw : tv;        // its block of columns
+  if (CH && (J < 0 || J >= a.nblocks)) return;
   const int nr = a.nr, nc = a.nc;
   double* __restrict__ v = a.v + (long)q * a.vstride;
   const double* __restrict__ f = a.f + (long)q * a.vstride;
-  u64* my_rec = a.carry + (long)q * a.carry_stride + (long)J * nr * 4;
-  const u64* left_rec = my_rec - (long)nr * 4;
+  const long rec_stride = (long)a.rec_rows * 4;  // granules per block
+  u64* my_rec = a.carry + (long)sw * a.sweep_stride + (long)q * a.carry_stride + (long)J * rec_stride;
+  const u64* left_rec = my_rec - rec_stride;
 
   const int i0 = J * 64 - (nc - 1) > 0 ? J * 64 - (nc - 1) : 0;  // first row with a column of this block inside the grid
   const int i1 = J * 64 + 63 < nr - 1 ? J * 64 + 63 : nr - 1;    // last one
@@ -107,8 +130,8 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // halo rows.  RAW = the window and the two columns right of it lie inside the grid on that row: no clamping, no masks.
   constexpr bool USE_W = OWN || !FIVE, USE_S2 = !FIVE;
   constexpr int kLoads = 3 + (USE_W ? 1 : 0) + (USE_S2 ? 1 : 0);  // per row: [W] S [S2] F + the edge record
-  constexpr int kOps = kLoads + 2;                                 // ... + the row's store and its record's store
-  constexpr int kSlots = kOps <= 5 ? 12 : (kOps == 6 ? 10 : 9);    // pipeline slots = rows in flight + the one in use
+  constexpr int kOps = kLoads + 2 + (CH ? 1 : 0);                  // ... + the row's store and its record's store (+ the chase record)
+  constexpr int kSlots = kOps <= 5 ? 12 : (kOps == 6 ? 10 : (kOps == 7 ? 9 : 8));  // pipeline slots = rows in flight + the one in use
   constexpr int kDepth = kSlots - 1;
   // The left block's record of row r is asked for kRec rows ahead only — not kDepth + 1 like the old values: a block can
   // run no closer behind its left neighbour than the distance at which its prefetched records come back complete, and the
@@ -116,11 +139,11 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // row i + kRec, old values of row i + kDepth + 1]; loads complete in order, so the wait of step i — for the record of row
   // i, issued kRec steps ago — lets only what was issued after it stay in flight.
   constexpr int kRec = 4;
-  constexpr int kWaitN = (kLoads - 1) + (kRec - 1) * kOps;
+  constexpr int kWaitN = (kLoads - 1) + (kRec - 1) * kOps;  // (the chase record, issued right behind the row's record, has landed too)
   static_assert(kWaitN <= 63, "vmcnt is a 6-bit counter");
   static_assert(kRec <= kDepth, "the old values of rows i, i + 1 are older than the record of row i");
   double Wv[kSlots], Sv[kSlots], S2v[kSlots], Fv[kSlots];
-  u64 Rv[kSlots];
+  u64 Rv[kSlots], Cv[kSlots];  // (Cv: the chase records — the sweep ahead's progress — of chained sweeps)
 #pragma unroll
   for (int d = 0; d < kSlots; ++d) {
     Wv[d] = 0.0;
@@ -128,6 +151,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     S2v[d] = 0.0;
     Fv[d] = 0.0;
     Rv[d] = 0;
+    Cv[d] = 0;
   }
   const u64* rec_src = J > 0 ? left_rec : my_rec;  // (block 0 has no left neighbour: any valid address, result unused)
   // issue the loads of the next row's old values into slot SL (rows are asked for in order: i0, i0 + 1, ...).  The
@@ -148,14 +172,20 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     const char *pv = ldv, *pf = ldf;                                   //  statement mentions is not captured)
     const unsigned off = lane8;
     if (decltype(plain)::value) {
-      if (USE_W) w_ = *reinterpret_cast<const double*>(pv + off);
-      s_ = *reinterpret_cast<const double*>(pv + off + 8);
-      if (USE_S2) s2_ = *reinterpret_cast<const double*>(pv + off + 16);
+      if (USE_W) w_ = load_value<CH>(pv + off);
+      s_ = load_value<CH>(pv + off + 8);
+      if (USE_S2) s2_ = load_value<CH>(pv + off + 16);
       f_ = *reinterpret_cast<const double*>(pf + off);
     } else {
-      if (USE_W) MGCMT_LEX_LOAD_AT(w_, off, pv, 0);
-      MGCMT_LEX_LOAD_AT(s_, off, pv, 8);
-      if (USE_S2) MGCMT_LEX_LOAD_AT(s2_, off, pv, 16);
+      if (CH) {  // (v is being rewritten by the sweep ahead: past the caches)
+        if (USE_W) MGCMT_LEX_LOAD_AT_SC1I(w_, off, pv, 0);
+        MGCMT_LEX_LOAD_AT_SC1I(s_, off, pv, 8);
+        if (USE_S2) MGCMT_LEX_LOAD_AT_SC1I(s2_, off, pv, 16);
+      } else {
+        if (USE_W) MGCMT_LEX_LOAD_AT(w_, off, pv, 0);
+        MGCMT_LEX_LOAD_AT(s_, off, pv, 8);
+        if (USE_S2) MGCMT_LEX_LOAD_AT(s2_, off, pv, 16);
+      }
       MGCMT_LEX_LOAD_AT(f_, off, pf, 0);
     }
     const long step = ld_r < nr ? row_stride : 0;  // (rows nr + 1 .. are never used: the pointer rests on row nr)
@@ -178,6 +208,36 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       MGCMT_LEX_LOAD_AT_SC1(r_, ro, rbase);
     }
     ldr += 4;
+  };
+
+  // the chase record that clears the loads of row R (chained sweeps, sweep > 0): record R + kRec of the sweep ahead's
+  // block J + 1 — or, while that block has not reached its first row (or does not exist), of its block J; rows behind a
+  // block's last one are its terminal records
+  const int Jn = J + 1 < a.nblocks ? J + 1 : J;
+  const int i0n = Jn * 64 - (nc - 1) > 0 ? Jn * 64 - (nc - 1) : 0;
+  const int i1n = Jn * 64 + 63 < nr - 1 ? Jn * 64 + 63 : nr - 1;
+  const u64* lead_own = my_rec - (CH ? a.sweep_stride : 0);
+  const u64* lead_next = lead_own + (long)(Jn - J) * rec_stride;
+  auto chase_ptr = [&](int R) __attribute__((always_inline)) {
+    const int cr = R + kRec;
+    const bool next = cr >= i0n;
+    const int cap = (next ? i1n : i1) + kTerminalRows;
+    return (next ? lead_next : lead_own) + (long)(cr < cap ? cr : cap) * 4;
+  };
+  auto chase_ok = [&](u64 R) __attribute__((always_inline)) {
+    const unsigned hi = (unsigned)(R >> 32);
+    return (lane_word(hi, 2) & lane_word(hi, 3)) == 1u;
+  };
+  auto issue_chase = [&](auto plain, auto slot, int R) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot)::value;
+    u64& c_ = Cv[SL];
+    const u64* cbase = sw > 0 ? chase_ptr(R) : my_rec;  // (the first sweep chases nobody: any valid address, result unused)
+    if (decltype(plain)::value) {
+      c_ = load_granule(cbase + (lane & 3));
+    } else {
+      const unsigned ro = roff;
+      MGCMT_LEX_LOAD_AT_SC1(c_, ro, cbase);
+    }
   };
 
   // edge records of the left block: the four granules of a row are read by lanes 0..3 (every lane loads, the address is
@@ -225,10 +285,30 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     }
   };
 
+  auto chase_wait = [&](int R) __attribute__((always_inline)) {  // the slow path of the chase: ask until the record is there
+    u64 t0 = 0;
+    bool timing = false;
+    const u64* p = chase_ptr(R) + (lane & 3);
+    while (true) {
+      if (chase_ok(load_granule(p))) return;
+      if (!timing) {
+        t0 = now_ticks();
+        timing = true;
+      }
+      nap();
+      if (now_ticks() - t0 > kTimeoutTicks || load_word(err_word) != 0u) {
+        failed = true;
+        return;
+      }
+    }
+  };
+
   // fill the pipeline: old values of rows i0 .. i0 + kDepth, records of rows i0 .. i0 + kRec - 1, with loads the compiler sees (it waits for them before the row loop's
   // first asm statement reads their registers; from then on nothing but the loop's own asm touches a slot)
+  if (CH && sw > 0) chase_wait(i0 + kSlots - 1);  // the sweep ahead has left the rows the prologue reads
   for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) { issue_old(Checked<true>{}, sl); });
   for_slots<kRec>([&](auto sl) __attribute__((always_inline)) { issue_rec(Checked<true>{}, sl); });
+  if (CH) for_slots<kRec>([&](auto sl) __attribute__((always_inline)) { issue_chase(Checked<true>{}, sl, i0 + decltype(sl)::value + kDepth + 1); });
   drain_loads();
   // The compiler does not know that the drain above completed its loads.  Left at that, it carries "slot k's load may be
   // pending" around the loop and puts its own s_waitcnt vmcnt(3 (kSlots - 1 - k)) before the first read of slot k in EVERY
@@ -241,6 +321,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     settle(S2v[d]);
     settle(Fv[d]);
     settle(Rv[d]);
+    settle(Cv[d]);
   }
 
   // rows on which every lane and everything its stencil reaches lies inside the grid: jmin >= 1 and jmin + 64 <= nc - 1 (- 2)
@@ -314,7 +395,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       // (an interior row has columns left of its window: the left block works on it)
       if (!unpack(rq_now, c1, c2)) wait_record(i, c1, c2);
       x = fma(qpow, c1, p);
-      *reinterpret_cast<double*>(vst + lane8) = x;
+      store_value<CH>(vst + lane8, x);
     } else {
       const int j = J * 64 - i + lane;
       const bool valid = (unsigned)j < (unsigned)nc;
@@ -414,7 +495,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
         x = fma(qmul, c1, p);
       }
       if (!FIVE && !valid) x = 0.0;
-      if (valid) *reinterpret_cast<double*>(vst + lane8) = x;
+      if (valid) store_value<CH>(vst + lane8, x);
     }
     {  // the row's edge record: {tag, half a double} granules, ONE store instruction (lanes 60..63; FIVE: 62, 63)
       const double t1 = from_right(x, lane);   // lane 62: x63, lane 61: x62
@@ -430,7 +511,8 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     const bool INTERIOR = (unsigned)(i - int_lo_eff) <= int_span;
     // the record of row i — and everything issued before it: the old values of rows i and i + 1 — has landed when at most
     // what was issued after it is in flight
-    wait_loads<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH]);
+    if (CH) wait_loads9<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH], Cv[PH]);
+    else wait_loads<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH]);
     double x, c1, c2;
     if (INTERIOR) row_body(ph, Checked<true>{}, i, x, c1, c2);
     else row_body(ph, Checked<false>{}, i, x, c1, c2);
@@ -444,6 +526,11 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     // slots would rotate through registers, and the copies that restore them at the loop's latch would read registers whose
     // loads are still in flight)
     issue_rec(Checked<false>{}, Int<(PH + kRec) % kSlots>{});
+    if (CH) {
+      // the row about to be asked for (ld_r = i + kDepth + 1): has the sweep ahead left it?  (its record came kRec steps ago)
+      if (sw > 0 && !chase_ok(Cv[PH])) chase_wait(ld_r);
+      issue_chase(Checked<false>{}, Int<(PH + kRec) % kSlots>{}, i + kRec + kDepth + 1);
+    }
     issue_old(Checked<false>{}, ph);
   };
   // ONE loop over the block's rows, kSlots rows per trip with compile-time phases; the last trip skips the rows behind i1
@@ -452,6 +539,11 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) {
       if (i + decltype(sl)::value <= i1) row_step(sl, i + decltype(sl)::value);
     });
+  if (CH && sw + 1 < nsw && !failed) {
+    // terminal records: every store of this block has been acknowledged (the sweep behind may read all of its rows)
+    drain_loads();
+    store_granule(my_rec + (long)(i1 + 1) * 4 + lane, 1ull << 32);
+  }
 #ifdef MGCMT_LEXWAVE_DEBUG
   if (lane == 0) {  // diagnostic build: per block {ticks (100 MHz), rows, slow-path entries} behind the two sync words
     unsigned* d = a.sync + 2 + 4 * (q * a.nblocks + J);
@@ -473,10 +565,12 @@ bool lex_wave_supported(const KGrid& g, const KOp& op) {
 
 long lex_wave_blocks(const KGrid& g) { return (g.nr + g.nc - 1 + 63) / 64; }
 
-// scratch: carry = k * blocks * nr * 4 granules of 8 bytes (cleared here: a record is valid when its tags are set),
-// sync = 2 words (cleared here)
+// scratch: carry = nsweeps * k * blocks * (nr + kTerminalRows) * 4 granules of 8 bytes (cleared here: a record is valid when
+// its tags are set), sync = 2 words (cleared here).  nsweeps > 1: that many sweeps chained in ONE launch (see k_lex_wave)
+long lex_wave_carry(const KGrid& g, int k, int nsweeps) { return (long)nsweeps * k * lex_wave_blocks(g) * (g.nr + kTerminalRows) * 4 + 64; }
+
 void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta, double wU,
-                     double wL, int k, double* carry, unsigned* sync) {
+                     double wL, int k, double* carry, unsigned* sync, int nsweeps) {
   LexWaveArgs a{};
   a.v = v.p;
   a.f = f.p;
@@ -508,13 +602,24 @@ void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.wL = wL;
   a.carry = reinterpret_cast<unsigned long long*>(carry);
   a.sync = sync;
-  a.carry_stride = (long)a.nblocks * g.nr * 4;
+  a.nsweeps = nsweeps < 1 ? 1 : nsweeps;
+  a.rec_rows = (int)g.nr + kTerminalRows;
+  a.carry_stride = (long)a.nblocks * a.rec_rows * 4;
+  a.sweep_stride = a.carry_stride * k;
   (void)hipMemsetAsync(sync, 0, sizeof(unsigned) * 2, s);
-  (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * (size_t)k * a.carry_stride, s);
-  const dim3 grid((unsigned)(a.nblocks * k));
-  if (a.five && alpha == 0.0) hipLaunchKernelGGL((k_lex_wave<true, false>), grid, dim3(64), 0, s, a);
-  else if (a.five) hipLaunchKernelGGL((k_lex_wave<true, true>), grid, dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((k_lex_wave<false, true>), grid, dim3(64), 0, s, a);
+  (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * (size_t)a.nsweeps * a.sweep_stride, s);
+  const bool five = op.five_point, own = alpha != 0.0 || !five;
+  if (a.nsweeps > 1) {
+    const dim3 grid((unsigned)((a.nblocks + 2 * (a.nsweeps - 1)) * a.nsweeps * k));
+    if (five && !own) hipLaunchKernelGGL((k_lex_wave<true, false, true>), grid, dim3(64), 0, s, a);
+    else if (five) hipLaunchKernelGGL((k_lex_wave<true, true, true>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_lex_wave<false, true, true>), grid, dim3(64), 0, s, a);
+  } else {
+    const dim3 grid((unsigned)(a.nblocks * k));
+    if (five && !own) hipLaunchKernelGGL((k_lex_wave<true, false, false>), grid, dim3(64), 0, s, a);
+    else if (five) hipLaunchKernelGGL((k_lex_wave<true, true, false>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_lex_wave<false, true, false>), grid, dim3(64), 0, s, a);
+  }
 }
 
 }  // namespace mgcmt

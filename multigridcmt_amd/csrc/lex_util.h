@@ -30,6 +30,8 @@ __device__ __forceinline__ int clamp0(int x, int hi) {
   asm volatile("global_load_dwordx2 %0, %1, %2 offset:" #imm : "+v"(dst) : "v"(off), "s"(base) : "memory")
 #define MGCMT_LEX_LOAD_AT_SC1(dst, off, base) \
   asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "+v"(dst) : "v"(off), "s"(base) : "memory")
+#define MGCMT_LEX_LOAD_AT_SC1I(dst, off, base, imm) \
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:" #imm " sc1" : "+v"(dst) : "v"(off), "s"(base) : "memory")
 #else
 __device__ __forceinline__ int uniform(int x) { return x; }
 __device__ __forceinline__ int clamp0(int x, int hi) { return x < 0 ? 0 : (x > hi ? hi : x); }
@@ -37,6 +39,7 @@ __device__ __forceinline__ int clamp0(int x, int hi) { return x < 0 ? 0 : (x > h
   (dst) = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (off) + (imm))
 #define MGCMT_LEX_LOAD_AT_SC1(dst, off, base) \
   (dst) = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(base) + (off))
+#define MGCMT_LEX_LOAD_AT_SC1I(dst, off, base, imm) MGCMT_LEX_LOAD_AT(dst, off, base, imm)
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -49,6 +52,11 @@ __device__ __forceinline__ void wait_loads(double& a, double& b, double& c, doub
 template <int N>
 __device__ __forceinline__ void wait_loads3(double& a, double& b, unsigned long long& r) {
   asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(r) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_loads9(double& a, double& b, double& c, double& d, double& e, double& f, double& g, unsigned long long& r,
+                                            unsigned long long& r2) {
+  asm volatile("s_waitcnt vmcnt(%9)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(r), "+v"(r2) : "n"(N) : "memory");
 }
 __device__ __forceinline__ void drain_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // the value of a slot that has landed, in a register of its own: a value that outlives the step (a stream history) must
@@ -69,6 +77,8 @@ template <int N>
 __device__ __forceinline__ void wait_loads(double&, double&, double&, double&, double&, double&, double&, unsigned long long&) {}
 template <int N>
 __device__ __forceinline__ void wait_loads3(double&, double&, unsigned long long&) {}
+template <int N>
+__device__ __forceinline__ void wait_loads9(double&, double&, double&, double&, double&, double&, double&, unsigned long long&, unsigned long long&) {}
 __device__ __forceinline__ void drain_loads() {}
 __device__ __forceinline__ double take(const double& slot) { return slot; }
 __device__ __forceinline__ void settle(double&) {}
@@ -100,6 +110,17 @@ __device__ __forceinline__ unsigned load_word(const unsigned* p) { return __hip_
 __device__ __forceinline__ void store_word(unsigned* p, unsigned x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 load_granule(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_granule(u64* p, u64 x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a double another workgroup of the same launch may have written / will read: agent scope (write-through, past the caches)
+template <bool SHARED>
+__device__ __forceinline__ double load_value(const char* p) {
+  if (SHARED) return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return *reinterpret_cast<const double*>(p);
+}
+template <bool SHARED>
+__device__ __forceinline__ void store_value(char* p, double x) {
+  if (SHARED) __hip_atomic_store(reinterpret_cast<u64*>(p), __builtin_bit_cast(u64, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *reinterpret_cast<double*>(p) = x;
+}
 __device__ __forceinline__ u64 now_ticks() { return wall_clock64(); }  // 100 MHz
 __device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(1); }
 #else
@@ -121,6 +142,10 @@ __device__ __forceinline__ unsigned load_word(const unsigned* p) { return *p; }
 __device__ __forceinline__ void store_word(unsigned* p, unsigned x) { *p = x; }
 __device__ __forceinline__ u64 load_granule(const u64* p) { return *p; }
 __device__ __forceinline__ void store_granule(u64* p, u64 x) { *p = x; }
+template <bool SHARED>
+__device__ __forceinline__ double load_value(const char* p) { return *reinterpret_cast<const double*>(p); }
+template <bool SHARED>
+__device__ __forceinline__ void store_value(char* p, double x) { *reinterpret_cast<double*>(p) = x; }
 __device__ __forceinline__ u64 now_ticks() { return 0; }
 __device__ __forceinline__ void nap() {}
 #endif

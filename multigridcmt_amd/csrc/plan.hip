@@ -276,13 +276,13 @@ namespace {
 
 // one generalised lexicographic sweep on vector slot `slot` (right-hand side: slot F): the wave pipeline where it
 // covers the level, the one-workgroup kernel otherwise
-int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double wU, double wL, int k, hipStream_t s) {
+int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double wU, double wL, int k, hipStream_t s, int nsweeps = 1) {
   const KGrid g = p->kgrid(l);
   const KOp& op = p->levels[l].dA.k;
   if (p->use_lex_wave && p->levels[l].nr == p->levels[l].gr && lex_wave_supported(g, op)) {
     const bool band = p->use_lex_wave == 2;
     const size_t blocks = (size_t)lex_wave_blocks(g);
-    const size_t need_scan = (size_t)p->nvec * blocks * g.nr * 4 + 64 /* the record prefetch runs a few rows past the last block's */, need_band = (size_t)p->nvec * lex_band_count(g) * lex_band_stride(g);
+    const size_t need_scan = (size_t)lex_wave_carry(g, p->nvec, nsweeps), need_band = (size_t)p->nvec * lex_band_count(g) * lex_band_stride(g);
     const size_t need_carry = band ? need_band : need_scan, need_sync = 2 + 4 * (size_t)p->nvec * blocks;  // (2 words used; the rest is the diagnostic build's per-block record)
     if (need_carry > p->lex_carry_doubles || need_sync > p->lex_sync_words) {
       MG_HIP(hipStreamSynchronize(s));
@@ -298,12 +298,20 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
       p->lex_carry_doubles = need_carry;
       p->lex_sync_words = need_sync;
     }
-    if (band) launch_lex_band(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync);
-    else launch_lex_wave(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync);
+    if (band) {
+      for (int it = 0; it < nsweeps; ++it)
+        launch_lex_band(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync);
+    } else if (p->lex_chain) {
+      launch_lex_wave(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync, nsweeps);
+    } else {
+      for (int it = 0; it < nsweeps; ++it)
+        launch_lex_wave(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync, 1);
+    }
     p->lex_wave_used = true;
     return MGCMT_OK;
   }
-  launch_lex_sweep(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k);
+  for (int it = 0; it < nsweeps; ++it)
+    launch_lex_sweep(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k);
   return MGCMT_OK;
 }
 
@@ -351,7 +359,7 @@ int smooth_impl(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hip
     case MGCMT_GS_LEX:
     case MGCMT_SOR_LEX: {
       if (kind == MGCMT_GS_LEX || omega == 1.0) {
-        for (int it = 0; it < nu; ++it) MG_TRY(lex_sweep(p, l, MGCMT_SLOT_V, 0.0, 1.0, 1.0, 1.0, k, s));
+        MG_TRY(lex_sweep(p, l, MGCMT_SLOT_V, 0.0, 1.0, 1.0, 1.0, k, s, nu));  // (nu sweeps, chained in one launch where the wave pipeline covers the level)
       } else {
         // reference SOR (MGCMTSolver.py:229-246): v <- (D-wL)^-1((1-w)D + wU) v + w (D-L)^-1 f.
         // T <- (D-L)^-1 f once, then per sweep the homogeneous recurrence followed by v += w T.
@@ -1184,6 +1192,11 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
   }
   if (option == MGCMT_OPT_LEX_WAVE) {
     p->use_lex_wave = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+    p->graphs_invalidate();
+    return MGCMT_OK;
+  }
+  if (option == MGCMT_OPT_LEX_CHAIN) {
+    p->lex_chain = value != 0;
     p->graphs_invalidate();
     return MGCMT_OK;
   }

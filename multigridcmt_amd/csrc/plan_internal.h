@@ -84,6 +84,7 @@ struct mgcmt_plan {
   double* lex_carry = nullptr;    // its scratch (grown on demand)
   unsigned* lex_sync = nullptr;
   size_t lex_carry_doubles = 0, lex_sync_words = 0;
+  bool lex_chain = true;          // consecutive Gauss-Seidel sweeps of a smoothing step run chained in one launch (kernels_lexwave.hip)
   bool lex_wave_used = false;     // the error word of lex_sync has not been looked at since the last sweep
   hipStream_t capture_stream = nullptr;
   struct CycleGraph {

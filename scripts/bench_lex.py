@@ -31,6 +31,10 @@ for g in (512, 1024, 4096, 16384):
             p.fill(1, _lib.SLOT_F, 0, 1.0); p.fill(1, _lib.SLOT_V, 0, 0.0)
             row["gs_sweep9_ms_" + tag] = timed(p, lambda: p.smooth(1, _lib.GS_LEX, 1, 1.0), n)
         row["gs_V22_ms_" + tag] = timed(p, lambda: p.vcycle(2, 2, _lib.GS_LEX, omega=1.0, nu_coarse=2), n)
+        if wave == 1:   # one launch per sweep instead of the sweeps of a smoothing step chained in one launch
+            p.set_option(_lib.OPT_LEX_CHAIN, 0)
+            row["gs_V22_ms_wave_unchained"] = timed(p, lambda: p.vcycle(2, 2, _lib.GS_LEX, omega=1.0, nu_coarse=2), n)
+            p.set_option(_lib.OPT_LEX_CHAIN, 1)
         row["gs_V44_ms_" + tag] = timed(p, lambda: p.vcycle(2, 2, _lib.GS_LEX, omega=1.0, nu_coarse=4), n)
         row["sor_V22_ms_" + tag] = timed(p, lambda: p.vcycle(2, 2, _lib.SOR_LEX, omega=1.3, nu_coarse=2), n)
         p.download(3, _lib.SLOT_V, 0)          # a synchronising call: raises if a block of the pipeline gave up

@@ -94,3 +94,31 @@ def test_lex_wave_4096_cycle_against_oracle(hip_only, pipeline):
     X, Y = st.laplacian_factors(g, "2d", SCALE)
     want = st.vcycle(X, Y, g, 8, 0.0, st.GS_LEX, np.zeros(g * g), f, 2, 2, 2, 1.0)
     assert rel_err(got, want) < 1e-10
+
+
+@pytest.mark.parametrize("g,level,nu", [(256, 0, 2), (256, 1, 4), (128, 0, 3), (64, 1, 2)])
+def test_chained_sweeps_equal_separate_sweeps(backend, g, level, nu):
+    """MGCMT_OPT_LEX_CHAIN: the nu Gauss-Seidel sweeps of a smoothing step in ONE launch (sweep s + 1 runs a few rows
+    behind sweep s, reading its results as they become visible) — the same arithmetic in the same order, so the same
+    bits as one launch per sweep; and both against the oracle."""
+    gl = g >> level
+    rng = np.random.RandomState(21)
+    k = 2
+    v0, f = rng.rand(k, gl * gl), rng.rand(k, gl * gl)
+    shifts = [0.0, 0.3]
+    outs = {}
+    for chain in (1, 0):
+        p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=k)
+        p.set_option(_lib.OPT_LEX_WAVE, 1)
+        p.set_option(_lib.OPT_LEX_CHAIN, chain)
+        p.set_shifts(shifts)
+        for q in range(k):
+            p.upload(level, _lib.SLOT_V, q, v0[q])
+            p.upload(level, _lib.SLOT_F, q, f[q])
+        p.smooth(level, _lib.GS_LEX, nu, 1.0, k=k)
+        outs[chain] = np.stack([p.download(level, _lib.SLOT_V, q) for q in range(k)])
+        p.close()
+    assert np.array_equal(outs[1], outs[0])
+    X, Y = _galerkin_factors(g, level)
+    for q in range(k):
+        assert rel_err(outs[1][q], st.smooth(X, Y, shifts[q], st.GS_LEX, v0[q], f[q], nu, 1.0)) < 1e-12
