@@ -44,6 +44,7 @@ struct LexWaveArgs {
   double crow[3], ccol[3], ccorner;  // last row: own-row coefficients (W, C, E); last column: centre column (N, C, S)
   const double* shifts;
   double alpha, beta, wU, wL;
+  double gamma;               // what is stored is x + gamma f (x goes on down the recurrence): reference SOR's v += w (D-L)^-1 f in the sweep
   unsigned long long* carry;  // [sweep][vector][block][row][4] granules {tag = 1 : 32, half of a double : 32}: lanes 62 / 63's new values
   unsigned* sync;             // [0] ticket, [1] error
   long carry_stride;          // granules per vector
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   if (i0 > i1) return;  // (cannot happen for nblocks = ceil((nr + nc - 1) / 64); kept as a guard)
 
   const double mu = a.shifts[q];
-  const double alpha = a.alpha, beta = a.beta, wU = a.wU, wL = a.wL;
+  const double alpha = a.alpha, beta = a.beta, wU = a.wU, wL = a.wL, gamma = a.gamma;
   // coefficient classes: interior, last column, last row, corner
   const double cNW = a.c[0][0], cNE = a.c[0][2], cSW = a.c[2][0], cSE = a.c[2][2];
   const double cN_int = a.c[0][1], cS_int = a.c[2][1], cW_int = a.c[1][0], cE_int = a.c[1][2];
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       // (an interior row has columns left of its window: the left block works on it)
       if (!unpack(rq_now, c1, c2)) wait_record(i, c1, c2);
       x = fma(qpow, c1, p);
-      store_value<CH>(vst + lane8, x);
+      store_value<CH>(vst + lane8, OWN ? fma(gamma, fv, x) : x);
     } else {
       const int j = J * 64 - i + lane;
       const bool valid = (unsigned)j < (unsigned)nc;
@@ -495,7 +496,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
         x = fma(qmul, c1, p);
       }
       if (!FIVE && !valid) x = 0.0;
-      if (valid) store_value<CH>(vst + lane8, x);
+      if (valid) store_value<CH>(vst + lane8, OWN ? fma(gamma, fv, x) : x);
     }
     {  // the row's edge record: {tag, half a double} granules, ONE store instruction (lanes 60..63; FIVE: 62, 63)
       const double t1 = from_right(x, lane);   // lane 62: x63, lane 61: x62
@@ -570,7 +571,7 @@ long lex_wave_blocks(const KGrid& g) { return (g.nr + g.nc - 1 + 63) / 64; }
 long lex_wave_carry(const KGrid& g, int k, int nsweeps) { return (long)nsweeps * k * lex_wave_blocks(g) * (g.nr + kTerminalRows) * 4 + 64; }
 
 void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta, double wU,
-                     double wL, int k, double* carry, unsigned* sync, int nsweeps) {
+                     double wL, int k, double* carry, unsigned* sync, int nsweeps, double gamma) {
   LexWaveArgs a{};
   a.v = v.p;
   a.f = f.p;
@@ -600,6 +601,7 @@ void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.beta = beta;
   a.wU = wU;
   a.wL = wL;
+  a.gamma = gamma;
   a.carry = reinterpret_cast<unsigned long long*>(carry);
   a.sync = sync;
   a.nsweeps = nsweeps < 1 ? 1 : nsweeps;
@@ -608,7 +610,7 @@ void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.sweep_stride = a.carry_stride * k;
   (void)hipMemsetAsync(sync, 0, sizeof(unsigned) * 2, s);
   (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * (size_t)a.nsweeps * a.sweep_stride, s);
-  const bool five = op.five_point, own = alpha != 0.0 || !five;
+  const bool five = op.five_point, own = alpha != 0.0 || gamma != 0.0 || !five;
   if (a.nsweeps > 1) {
     const dim3 grid((unsigned)((a.nblocks + 2 * (a.nsweeps - 1)) * a.nsweeps * k));
     if (five && !own) hipLaunchKernelGGL((k_lex_wave<true, false, true>), grid, dim3(64), 0, s, a);

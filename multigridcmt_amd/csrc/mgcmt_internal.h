@@ -68,7 +68,7 @@ bool lex_wave_supported(const KGrid& g, const KOp& op);
 long lex_wave_blocks(const KGrid& g);
 long lex_wave_carry(const KGrid& g, int k, int nsweeps);  // granules of `carry` for k vectors and nsweeps chained sweeps
 void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta, double wU,
-                     double wL, int k, double* carry, unsigned* sync, int nsweeps);
+                     double wL, int k, double* carry, unsigned* sync, int nsweeps, double gamma);
 // ... and as a wavefront over bands of 63 rows (kernels_lexband.hip; same operators and grids).  carry: k *
 // lex_band_count(g) * lex_band_stride(g) eight-byte granules; sync as above
 long lex_band_count(const KGrid& g);

@@ -274,9 +274,15 @@ int pass_sweeps(const mgcmt_plan* p, int l, int kind, int left) {
 }  // namespace mgcmt
 namespace {
 
-// one generalised lexicographic sweep on vector slot `slot` (right-hand side: slot F): the wave pipeline where it
-// covers the level, the one-workgroup kernel otherwise
-int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double wU, double wL, int k, hipStream_t s, int nsweeps = 1) {
+// nsweeps generalised lexicographic sweeps on vector slot `slot` (right-hand side: slot `fslot`), each followed by
+// slot += gamma * fslot: the wave pipeline where it covers the level (sweeps chained in one launch, the update inside
+// the sweep), the one-workgroup kernel otherwise
+int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double wU, double wL, int k, hipStream_t s, int nsweeps = 1,
+              double gamma = 0.0, int fslot = MGCMT_SLOT_F) {
+  auto update = [&]() {
+    if (gamma != 0.0)
+      for (int q = 0; q < k; ++q) launch_axpy(s, p->interior(l), gamma, p->kvec(l, fslot, q).p, p->kvec(l, slot, q).p);
+  };
   const KGrid g = p->kgrid(l);
   const KOp& op = p->levels[l].dA.k;
   if (p->use_lex_wave && p->levels[l].nr == p->levels[l].gr && lex_wave_supported(g, op)) {
@@ -299,19 +305,23 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
       p->lex_sync_words = need_sync;
     }
     if (band) {
-      for (int it = 0; it < nsweeps; ++it)
-        launch_lex_band(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync);
+      for (int it = 0; it < nsweeps; ++it) {
+        launch_lex_band(s, g, op, p->kvec(l, slot), p->kvec(l, fslot), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync);
+        update();
+      }
     } else if (p->lex_chain) {
-      launch_lex_wave(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync, nsweeps);
+      launch_lex_wave(s, g, op, p->kvec(l, slot), p->kvec(l, fslot), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync, nsweeps, gamma);
     } else {
       for (int it = 0; it < nsweeps; ++it)
-        launch_lex_wave(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync, 1);
+        launch_lex_wave(s, g, op, p->kvec(l, slot), p->kvec(l, fslot), p->d_shifts, alpha, beta, wU, wL, k, p->lex_carry, p->lex_sync, 1, gamma);
     }
     p->lex_wave_used = true;
     return MGCMT_OK;
   }
-  for (int it = 0; it < nsweeps; ++it)
-    launch_lex_sweep(s, g, op, p->kvec(l, slot), p->kvec(l, MGCMT_SLOT_F), p->d_shifts, alpha, beta, wU, wL, k);
+  for (int it = 0; it < nsweeps; ++it) {
+    launch_lex_sweep(s, g, op, p->kvec(l, slot), p->kvec(l, fslot), p->d_shifts, alpha, beta, wU, wL, k);
+    update();
+  }
   return MGCMT_OK;
 }
 
@@ -366,10 +376,8 @@ int smooth_impl(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hip
         MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
         for (int q = 0; q < k; ++q) launch_fill(s, p->kvec(l, MGCMT_SLOT_T, q).p, p->interior(l), 0.0);
         MG_TRY(lex_sweep(p, l, MGCMT_SLOT_T, 0.0, 1.0, 0.0, 1.0, k, s));
-        for (int it = 0; it < nu; ++it) {
-          MG_TRY(lex_sweep(p, l, MGCMT_SLOT_V, 1.0 - omega, 0.0, omega, omega, k, s));
-          for (int q = 0; q < k; ++q) launch_axpy(s, p->interior(l), omega, p->kvec(l, MGCMT_SLOT_T, q).p, p->kvec(l, MGCMT_SLOT_V, q).p);
-        }
+        // (beta = 0: the sweeps do not read their right-hand side — T rides in its place and is added as it is stored)
+        MG_TRY(lex_sweep(p, l, MGCMT_SLOT_V, 1.0 - omega, 0.0, omega, omega, k, s, nu, omega, MGCMT_SLOT_T));
       }
       break;
     }
