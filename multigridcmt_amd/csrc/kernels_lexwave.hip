@@ -229,15 +229,30 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     const unsigned hi = (unsigned)(R >> 32);
     return (lane_word(hi, 2) & lane_word(hi, 3)) == 1u;
   };
-  auto issue_chase = [&](auto plain, auto slot, int R) __attribute__((always_inline)) {
+  // ... asked for in order (R = i0 + kDepth + 1, i0 + kDepth + 2, ...) from a running pointer: it moves on by a row until
+  // the terminal records' last one, and jumps once, when the sweep ahead's block J + 1 reaches its first row.  The first
+  // sweep chases nobody: its pointer rests on its own records (any valid address; the result is not looked at)
+  int ch_r = i0 + kDepth + 1 + kRec;  // the record row the pointer stands on (first sweep: never compared with anything reachable)
+  const u64* ch_p = CH && sw > 0 ? chase_ptr(i0 + kDepth + 1) : my_rec;
+  const int ch_jump = CH && sw > 0 && Jn != J ? i0n : -1;                  // the row at which the pointer changes blocks
+  int ch_cap = CH && sw > 0 ? (ch_r >= i0n ? i1n : i1) + kTerminalRows : -1;  // the last row the pointer moves up to
+  auto issue_chase = [&](auto plain, auto slot) __attribute__((always_inline)) {
     constexpr int SL = decltype(slot)::value;
     u64& c_ = Cv[SL];
-    const u64* cbase = sw > 0 ? chase_ptr(R) : my_rec;  // (the first sweep chases nobody: any valid address, result unused)
+    const u64* cbase = ch_p;
     if (decltype(plain)::value) {
       c_ = load_granule(cbase + (lane & 3));
     } else {
       const unsigned ro = roff;
       MGCMT_LEX_LOAD_AT_SC1(c_, ro, cbase);
+    }
+    if (ch_r + 1 == ch_jump) {  // (once per block at most)
+      ch_p = lead_next + (long)ch_jump * 4;
+      ch_cap = i1n + kTerminalRows;
+      ++ch_r;
+    } else if (ch_r < ch_cap) {
+      ch_p += 4;
+      ++ch_r;
     }
   };
 
@@ -309,7 +324,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   if (CH && sw > 0) chase_wait(i0 + kSlots - 1);  // the sweep ahead has left the rows the prologue reads
   for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) { issue_old(Checked<true>{}, sl); });
   for_slots<kRec>([&](auto sl) __attribute__((always_inline)) { issue_rec(Checked<true>{}, sl); });
-  if (CH) for_slots<kRec>([&](auto sl) __attribute__((always_inline)) { issue_chase(Checked<true>{}, sl, i0 + decltype(sl)::value + kDepth + 1); });
+  if (CH) for_slots<kRec>([&](auto sl) __attribute__((always_inline)) { issue_chase(Checked<true>{}, sl); });
   drain_loads();
   // The compiler does not know that the drain above completed its loads.  Left at that, it carries "slot k's load may be
   // pending" around the loop and puts its own s_waitcnt vmcnt(3 (kSlots - 1 - k)) before the first read of slot k in EVERY
@@ -530,7 +545,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     if (CH) {
       // the row about to be asked for (ld_r = i + kDepth + 1): has the sweep ahead left it?  (its record came kRec steps ago)
       if (sw > 0 && !chase_ok(Cv[PH])) chase_wait(ld_r);
-      issue_chase(Checked<false>{}, Int<(PH + kRec) % kSlots>{}, i + kRec + kDepth + 1);
+      issue_chase(Checked<false>{}, Int<(PH + kRec) % kSlots>{});
     }
     issue_old(Checked<false>{}, ph);
   };

@@ -48,8 +48,31 @@ def run(args, backend="nccl", on_gpu=True):
     kind = _lib.WJACOBI if args.smoother == "wjacobi" else _lib.GS_MC
     omega = 2.0 / 3.0 if args.smoother == "wjacobi" else 1.0
     op = laplacian_operator(g, "2d") * (-1.0 / np.pi ** 2)
-    sp = ShardedPlan(op, args.lowest, rank, world, device=local, switch_grid=getattr(args, "switch_grid", None), on_gpu=on_gpu,
-                     transport=transport, unique_id=uid)
+    def make_plan(tr):
+        return ShardedPlan(op, args.lowest, rank, world, device=local, switch_grid=getattr(args, "switch_grid", None), on_gpu=on_gpu,
+                           transport=tr, unique_id=uid if tr == "rccl" else None)
+
+    # The in-library RCCL transport has only ever run at world size 1 on the builder's one-GPU boxes.  If any rank cannot
+    # bring it up, EVERY rank falls back to the torch.distributed transport (the same RCCL underneath, called through
+    # callbacks from the library) — a different way to move the halo rows, not a different compute path; the line says which.
+    sp, err = None, None
+    try:
+        sp = make_plan(transport)
+    except Exception as e:                                   # noqa: BLE001 (reported below)
+        err = e
+    if transport == "rccl" and world > 1:
+        ok = torch.tensor([0 if sp is None else 1], dtype=torch.int32, device=("cuda:%d" % local) if on_gpu else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if sp is not None:
+                sp.close()
+            if rank == 0:
+                import sys
+                print("bench: RCCL transport unavailable (%r): falling back to the torch.distributed transport" % (err,), file=sys.stderr)
+            transport = "torch"
+            sp = make_plan(transport)
+    elif sp is None:
+        raise err
     sp.set_shift(0.0)
     rows = g // world
     sp.upload_local(_lib.SLOT_F, np.random.RandomState(1 + rank).rand(rows * g))   # this rank's rows of the right-hand side
