@@ -49,26 +49,32 @@ struct LexWaveArgs {
   unsigned* sync;             // [0] ticket, [1] error
   long carry_stride;          // granules per vector
   int nsweeps;                // sweeps chained in this launch (1: the plain sweep)
+  int nvec;                   // vectors in this launch
+  unsigned long long* progress;  // [sweep][vector][block] rows finished with all stores acknowledged (chained sweeps; cleared per launch)
   int rec_rows;               // rows of a block's record array: nr + kTerminalRows
   long sweep_stride;          // granules per sweep
 };
 
-// rows of "terminal" records a block of a chained sweep appends to its own: present = the block has finished and every
-// store of it has been acknowledged
-constexpr int kTerminalRows = 16;
+constexpr int kTerminalRows = 16;  // (spare rows behind a block's records: the record prefetch runs a few rows past the last one)
+#ifndef MGCMT_LEX_CHAIN_REC
+#define MGCMT_LEX_CHAIN_REC 4  // chained sweeps: rows ahead at which records are asked for (tuning)
+#endif
 
 // FIVE: constant 5-point operator (no corner terms, no special last row / column); OWN: the sweep uses the point's own
 // old value (alpha != 0: the homogeneous SOR recurrence); CH: several sweeps chained in one launch.
 //
 // Chained sweeps (CH): sweep s runs behind sweep s - 1 on the same vector, in the same launch.  Block (s, J) may read the
-// old values of its rows i, i + 1 — sweep s - 1's results in its own window and the two columns right of it — once blocks J
-// and J + 1 of sweep s - 1 have finished row i + 1 AND their stores are visible.  Stores of v are write-through and loads
-// of v bypass the caches in these kernels; a block's record of row r is written after the wait at the top of step r, which
-// (memory operations complete in order) has seen the stores of rows <= r - kRec acknowledged.  So "record (R + kRec) of
-// block J + 1 of sweep s - 1 is there" says: that block's rows <= R are visible, and — it has consumed block J's record
-// of row R + kRec to get there — so are block J's.  Block (s, J) asks for that record before it issues the loads of row
-// R, kRec steps ahead like its own left neighbour's record, and spins (bounded) when it is not there yet.  Blocks get
-// their numbers in the order of (J + 2 s, s), so a block only ever waits for blocks that have started.
+// old values of a row R — sweep s - 1's results in its own window and the two columns right of it — once blocks J and J + 1
+// of sweep s - 1 have finished row R AND those stores are visible.  The hand-off is the one MI355X_MICROARCH.md lists as
+// valid without an acquire: every store of v in these kernels is `sc1` (write-through), every load of v an `sc1` load to
+// registers; a block of the sweep ahead publishes its progress every few trips of its row loop — `s_waitcnt vmcnt(0)` (all of its
+// stores acknowledged), then ONE `sc1` store of the number of rows it has finished — and the block behind polls that
+// number with `sc1` loads before the trip that issues the loads of a row, keeping the last value it saw (so it polls
+// about as often as the block ahead publishes).  (An earlier form took the sweep ahead's per-row edge records as the
+// progress signal, behind the row loop's partial `vmcnt(N)` wait instead of a drain.  It gave the same bits on every
+// level of a 16384^2 plan, but that wait is not the drain the guide's form asks for, and it cost a load, a tag check
+// and pointer arithmetic per row in every block: 8.3 against 7.4 ms per 4096^2 V(2,2) cycle.)
+// Blocks get their numbers in the order of (J + 2 s, s), so a block only ever waits for blocks that have started.
 template <bool FIVE, bool OWN, bool CH>
 __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   const int lane = threadIdx.x;
@@ -131,7 +137,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // halo rows.  RAW = the window and the two columns right of it lie inside the grid on that row: no clamping, no masks.
   constexpr bool USE_W = OWN || !FIVE, USE_S2 = !FIVE;
   constexpr int kLoads = 3 + (USE_W ? 1 : 0) + (USE_S2 ? 1 : 0);  // per row: [W] S [S2] F + the edge record
-  constexpr int kOps = kLoads + 2 + (CH ? 1 : 0);                  // ... + the row's store and its record's store (+ the chase record)
+  constexpr int kOps = kLoads + 2;                                 // ... + the row's store and its record's store
   constexpr int kSlots = kOps <= 5 ? 12 : (kOps == 6 ? 10 : (kOps == 7 ? 9 : 8));  // pipeline slots = rows in flight + the one in use
   constexpr int kDepth = kSlots - 1;
   // The left block's record of row r is asked for kRec rows ahead only — not kDepth + 1 like the old values: a block can
@@ -139,12 +145,13 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // sum of those lags over the blocks is the sweep's start-up time.  A step issues [row store, record store, record load of
   // row i + kRec, old values of row i + kDepth + 1]; loads complete in order, so the wait of step i — for the record of row
   // i, issued kRec steps ago — lets only what was issued after it stay in flight.
-  constexpr int kRec = 4;
-  constexpr int kWaitN = (kLoads - 1) + (kRec - 1) * kOps;  // (the chase record, issued right behind the row's record, has landed too)
+  constexpr int kRec = CH ? MGCMT_LEX_CHAIN_REC : 4;  // (chained sweeps load v past the caches: the longer latency wants more steps between a load and the wait behind it)
+  constexpr int kProgressTrips = 3;                   // chained sweeps: trips (of kSlots rows) between two publications of a block's progress
+  constexpr int kWaitN = (kLoads - 1) + (kRec - 1) * kOps;
   static_assert(kWaitN <= 63, "vmcnt is a 6-bit counter");
-  static_assert(kRec <= kDepth, "the old values of rows i, i + 1 are older than the record of row i");
+  static_assert(kRec < kDepth, "the old values of rows i, i + 1 are older than the record of row i (row i + 1 is asked for kDepth steps ahead, behind that step's record)");
   double Wv[kSlots], Sv[kSlots], S2v[kSlots], Fv[kSlots];
-  u64 Rv[kSlots], Cv[kSlots];  // (Cv: the chase records — the sweep ahead's progress — of chained sweeps)
+  u64 Rv[kSlots];
 #pragma unroll
   for (int d = 0; d < kSlots; ++d) {
     Wv[d] = 0.0;
@@ -152,7 +159,6 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     S2v[d] = 0.0;
     Fv[d] = 0.0;
     Rv[d] = 0;
-    Cv[d] = 0;
   }
   const u64* rec_src = J > 0 ? left_rec : my_rec;  // (block 0 has no left neighbour: any valid address, result unused)
   // issue the loads of the next row's old values into slot SL (rows are asked for in order: i0, i0 + 1, ...).  The
@@ -211,51 +217,14 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     ldr += 4;
   };
 
-  // the chase record that clears the loads of row R (chained sweeps, sweep > 0): record R + kRec of the sweep ahead's
-  // block J + 1 — or, while that block has not reached its first row (or does not exist), of its block J; rows behind a
-  // block's last one are its terminal records
+  // chained sweeps: the progress words (rows finished, all stores acknowledged) of this block and of the two blocks of
+  // the sweep ahead whose results this block reads: its own column block J and J + 1 (which only matters from its first
+  // row on; the last block has no right neighbour)
   const int Jn = J + 1 < a.nblocks ? J + 1 : J;
   const int i0n = Jn * 64 - (nc - 1) > 0 ? Jn * 64 - (nc - 1) : 0;
-  const int i1n = Jn * 64 + 63 < nr - 1 ? Jn * 64 + 63 : nr - 1;
-  const u64* lead_own = my_rec - (CH ? a.sweep_stride : 0);
-  const u64* lead_next = lead_own + (long)(Jn - J) * rec_stride;
-  auto chase_ptr = [&](int R) __attribute__((always_inline)) {
-    const int cr = R + kRec;
-    const bool next = cr >= i0n;
-    const int cap = (next ? i1n : i1) + kTerminalRows;
-    return (next ? lead_next : lead_own) + (long)(cr < cap ? cr : cap) * 4;
-  };
-  auto chase_ok = [&](u64 R) __attribute__((always_inline)) {
-    const unsigned hi = (unsigned)(R >> 32);
-    return (lane_word(hi, 2) & lane_word(hi, 3)) == 1u;
-  };
-  // ... asked for in order (R = i0 + kDepth + 1, i0 + kDepth + 2, ...) from a running pointer: it moves on by a row until
-  // the terminal records' last one, and jumps once, when the sweep ahead's block J + 1 reaches its first row.  The first
-  // sweep chases nobody: its pointer rests on its own records (any valid address; the result is not looked at)
-  int ch_r = i0 + kDepth + 1 + kRec;  // the record row the pointer stands on (first sweep: never compared with anything reachable)
-  const u64* ch_p = CH && sw > 0 ? chase_ptr(i0 + kDepth + 1) : my_rec;
-  const int ch_jump = CH && sw > 0 && Jn != J ? i0n : -1;                  // the row at which the pointer changes blocks
-  int ch_cap = CH && sw > 0 ? (ch_r >= i0n ? i1n : i1) + kTerminalRows : -1;  // the last row the pointer moves up to
-  auto issue_chase = [&](auto plain, auto slot) __attribute__((always_inline)) {
-    constexpr int SL = decltype(slot)::value;
-    u64& c_ = Cv[SL];
-    const u64* cbase = ch_p;
-    if (decltype(plain)::value) {
-      c_ = load_granule(cbase + (lane & 3));
-    } else {
-      const unsigned ro = roff;
-      MGCMT_LEX_LOAD_AT_SC1(c_, ro, cbase);
-    }
-    if (ch_r + 1 == ch_jump) {  // (once per block at most)
-      ch_p = lead_next + (long)ch_jump * 4;
-      ch_cap = i1n + kTerminalRows;
-      ++ch_r;
-    } else if (ch_r < ch_cap) {
-      ch_p += 4;
-      ++ch_r;
-    }
-  };
-
+  u64* const my_prog = a.progress + ((long)sw * a.nvec + q) * a.nblocks + J;
+  const u64* const lead_prog = my_prog - (long)a.nvec * a.nblocks;  // (sweep > 0 only)
+  int seen_own = 0, seen_next = 0;  // rows of the sweep ahead known to be finished and visible
   // edge records of the left block: the four granules of a row are read by lanes 0..3 (every lane loads, the address is
   // clamped), kRec rows before they are needed; the slow path asks again, visibly
   auto load_record = [&](int row) __attribute__((always_inline)) {
@@ -301,12 +270,15 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     }
   };
 
-  auto chase_wait = [&](int R) __attribute__((always_inline)) {  // the slow path of the chase: ask until the record is there
+  // row R of the sweep ahead is finished and visible (blocks J and, from its first row on, J + 1): the loads of row R may
+  // be issued.  Polls (bounded) only when the values seen last do not cover R
+  auto chase = [&](int R) __attribute__((always_inline)) {
     u64 t0 = 0;
     bool timing = false;
-    const u64* p = chase_ptr(R) + (lane & 3);
-    while (true) {
-      if (chase_ok(load_granule(p))) return;
+    while (seen_own <= R || (R >= i0n && seen_next <= R)) {
+      seen_own = (int)uniform((int)load_granule(lead_prog));
+      seen_next = (int)uniform((int)load_granule(lead_prog + (Jn - J)));
+      if (seen_own > R && !(R >= i0n && seen_next <= R)) break;
       if (!timing) {
         t0 = now_ticks();
         timing = true;
@@ -321,10 +293,9 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
 
   // fill the pipeline: old values of rows i0 .. i0 + kDepth, records of rows i0 .. i0 + kRec - 1, with loads the compiler sees (it waits for them before the row loop's
   // first asm statement reads their registers; from then on nothing but the loop's own asm touches a slot)
-  if (CH && sw > 0) chase_wait(i0 + kSlots - 1);  // the sweep ahead has left the rows the prologue reads
+  if (CH && sw > 0) chase(i0 + kSlots - 1 < nr ? i0 + kSlots - 1 : nr - 1);  // the sweep ahead has left the rows the prologue reads
   for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) { issue_old(Checked<true>{}, sl); });
   for_slots<kRec>([&](auto sl) __attribute__((always_inline)) { issue_rec(Checked<true>{}, sl); });
-  if (CH) for_slots<kRec>([&](auto sl) __attribute__((always_inline)) { issue_chase(Checked<true>{}, sl); });
   drain_loads();
   // The compiler does not know that the drain above completed its loads.  Left at that, it carries "slot k's load may be
   // pending" around the loop and puts its own s_waitcnt vmcnt(3 (kSlots - 1 - k)) before the first read of slot k in EVERY
@@ -337,7 +308,6 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     settle(S2v[d]);
     settle(Fv[d]);
     settle(Rv[d]);
-    settle(Cv[d]);
   }
 
   // rows on which every lane and everything its stencil reaches lies inside the grid: jmin >= 1 and jmin + 64 <= nc - 1 (- 2)
@@ -527,8 +497,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     const bool INTERIOR = (unsigned)(i - int_lo_eff) <= int_span;
     // the record of row i — and everything issued before it: the old values of rows i and i + 1 — has landed when at most
     // what was issued after it is in flight
-    if (CH) wait_loads9<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH], Cv[PH]);
-    else wait_loads<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH]);
+    wait_loads<kWaitN>(Wv[PH], Sv[PH], Fv[PH], Wv[NEXT], Sv[NEXT], S2v[NEXT], S2v[PH], Rv[PH]);
     double x, c1, c2;
     if (INTERIOR) row_body(ph, Checked<true>{}, i, x, c1, c2);
     else row_body(ph, Checked<false>{}, i, x, c1, c2);
@@ -542,23 +511,28 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
     // slots would rotate through registers, and the copies that restore them at the loop's latch would read registers whose
     // loads are still in flight)
     issue_rec(Checked<false>{}, Int<(PH + kRec) % kSlots>{});
-    if (CH) {
-      // the row about to be asked for (ld_r = i + kDepth + 1): has the sweep ahead left it?  (its record came kRec steps ago)
-      if (sw > 0 && !chase_ok(Cv[PH])) chase_wait(ld_r);
-      issue_chase(Checked<false>{}, Int<(PH + kRec) % kSlots>{});
-    }
     issue_old(Checked<false>{}, ph);
   };
   // ONE loop over the block's rows, kSlots rows per trip with compile-time phases; the last trip skips the rows behind i1
   // (a skipped step issues nothing, and nothing behind it consumes)
-  for (int i = i0; i <= i1 && !failed; i += kSlots)
+  for (int i = i0; i <= i1 && !failed; i += kSlots) {
+    if (CH) {
+      // Once per trip, OUTSIDE the unrolled row steps (a polling loop inside them made the compiler move the slots: the
+      // audit).  Publish: rows < i are finished, and — after the drain — every store of them has been acknowledged.
+      if (sw + 1 < nsw && i > i0 && ((i - i0) / kSlots) % kProgressTrips == 0) {
+        drain_loads();
+        store_granule(my_prog, (u64)i);
+      }
+      // Chase: this trip asks for rows up to i + 2 kSlots - 1 (rows behind the grid's last read the halo)
+      if (sw > 0) chase(i + 2 * kSlots - 1 < nr ? i + 2 * kSlots - 1 : nr - 1);
+    }
     for_slots<kSlots>([&](auto sl) __attribute__((always_inline)) {
       if (i + decltype(sl)::value <= i1) row_step(sl, i + decltype(sl)::value);
     });
-  if (CH && sw + 1 < nsw && !failed) {
-    // terminal records: every store of this block has been acknowledged (the sweep behind may read all of its rows)
+  }
+  if (CH && sw + 1 < nsw && !failed) {  // finished: every row, for good (the sweep behind never asks for more than nr rows)
     drain_loads();
-    store_granule(my_rec + (long)(i1 + 1) * 4 + lane, 1ull << 32);
+    store_granule(my_prog, (u64)(nr + 1));
   }
 #ifdef MGCMT_LEXWAVE_DEBUG
   if (lane == 0) {  // diagnostic build: per block {ticks (100 MHz), rows, slow-path entries} behind the two sync words
@@ -583,7 +557,9 @@ long lex_wave_blocks(const KGrid& g) { return (g.nr + g.nc - 1 + 63) / 64; }
 
 // scratch: carry = nsweeps * k * blocks * (nr + kTerminalRows) * 4 granules of 8 bytes (cleared here: a record is valid when
 // its tags are set), sync = 2 words (cleared here).  nsweeps > 1: that many sweeps chained in ONE launch (see k_lex_wave)
-long lex_wave_carry(const KGrid& g, int k, int nsweeps) { return (long)nsweeps * k * lex_wave_blocks(g) * (g.nr + kTerminalRows) * 4 + 64; }
+long lex_wave_carry(const KGrid& g, int k, int nsweeps) {
+  return (long)nsweeps * k * lex_wave_blocks(g) * ((g.nr + kTerminalRows) * 4 + 1) + 64;  // (records + one progress word per block)
+}
 
 void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta, double wU,
                      double wL, int k, double* carry, unsigned* sync, int nsweeps, double gamma) {
@@ -623,8 +599,10 @@ void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.rec_rows = (int)g.nr + kTerminalRows;
   a.carry_stride = (long)a.nblocks * a.rec_rows * 4;
   a.sweep_stride = a.carry_stride * k;
+  a.nvec = k;
+  a.progress = a.carry + (long)a.nsweeps * a.sweep_stride;
   (void)hipMemsetAsync(sync, 0, sizeof(unsigned) * 2, s);
-  (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * (size_t)a.nsweeps * a.sweep_stride, s);
+  (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * ((size_t)a.nsweeps * a.sweep_stride + (size_t)a.nsweeps * k * a.nblocks), s);
   const bool five = op.five_point, own = alpha != 0.0 || gamma != 0.0 || !five;
   if (a.nsweeps > 1) {
     const dim3 grid((unsigned)((a.nblocks + 2 * (a.nsweeps - 1)) * a.nsweeps * k));

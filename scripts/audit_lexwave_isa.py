@@ -47,8 +47,9 @@ def audit(path, kernel="k_lex_wave"):
         loop = [l.strip() for l in body[headers[-1]:]]
         dests = set()
         seen = {}
-        for t in loop:
-            m = re.search(r"global_load_dwordx2 v\[(\d+):(\d+)\], v\d+, s\[", t)
+        for n, t in enumerate(loop):
+            # (hand-counted = inside an asm statement: the compiler's own loads can take the same scalar-base form)
+            m = re.search(r"global_load_dwordx2 v\[(\d+):(\d+)\], v\d+, s\[", t) if n and "#ASMSTART" in loop[n - 1] else None
             if m:
                 dests.update({int(m.group(1)), int(m.group(2))})
                 seen[m.group(1)] = seen.get(m.group(1), 0) + 1

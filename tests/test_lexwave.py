@@ -122,3 +122,24 @@ def test_chained_sweeps_equal_separate_sweeps(backend, g, level, nu):
     X, Y = _galerkin_factors(g, level)
     for q in range(k):
         assert rel_err(outs[1][q], st.smooth(X, Y, shifts[q], st.GS_LEX, v0[q], f[q], nu, 1.0)) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g,kind,omega", [(16384, _lib.GS_LEX, 1.0), (8192, _lib.SOR_LEX, 1.3)])
+def test_chained_cycle_equals_unchained_at_size(hip_only, g, kind, omega):
+    """Thousands of waves, hand-offs and chases under load: three V(2,2) cycles with the sweeps of every smoothing step
+    chained in one launch give the bits of one launch per sweep (visibility of the sweep ahead's stores is the one thing
+    the emulation cannot check)."""
+    f = np.random.RandomState(12).rand(g * g)
+    outs = []
+    for chain in (1, 0):
+        p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
+        p.set_option(_lib.OPT_LEX_CHAIN, chain)
+        p.set_shifts([0.0])
+        p.upload(0, _lib.SLOT_F, 0, f)
+        p.fill(0, _lib.SLOT_V, 0, 0.0)
+        for _ in range(3):
+            p.vcycle(2, 2, kind, omega=omega, nu_coarse=4)
+        outs.append(np.array(p.download(0, _lib.SLOT_V, 0)))
+        p.close()
+    assert np.array_equal(outs[0], outs[1])
