@@ -158,6 +158,14 @@ int mgcmt_rayleigh_residual(mgcmt_plan* plan, int level, int slot, int k, double
 int mgcmt_lincomb(mgcmt_plan* plan, int level, int nterms, const double* coeffs, const int* slots, const int* vecs, int dst_slot,
                   int dst_vec, void* stream);
 int mgcmt_scale(mgcmt_plan* plan, int level, double alpha, int slot, int vec, void* stream);
+/* Block operations of the blocked Rayleigh-Ritz eigen-solver (the 2-vector problem of rqmin, MGCMTSolver.py:44-50, carried
+ * to blocks of trial vectors; SURVEY par. 8(f)4).  block_gram: out[i * nb + j] = <A_i, B_j> for na <= 12 and nb <= 4
+ * vectors in one pass, synchronises.  block_combine: OUT_j = sum_i coeffs[i * nout + j] IN_i for nin <= 12 inputs and
+ * nout <= 4 distinct outputs, every input read once; an output may be one of the inputs. */
+int mgcmt_block_gram(mgcmt_plan* plan, int level, int na, const int* a_slots, const int* a_vecs, int nb, const int* b_slots,
+                     const int* b_vecs, double* out, void* stream);
+int mgcmt_block_combine(mgcmt_plan* plan, int level, int nin, const int* in_slots, const int* in_vecs, int nout, const int* out_slots,
+                        const int* out_vecs, const double* coeffs, void* stream);
 /* in-place Gram-Schmidt of vectors 0..k-1 of `slot`: modified != 0 -> MGS (:44-50), else CGS (:34-42) */
 int mgcmt_gramschmidt(mgcmt_plan* plan, int level, int slot, int k, int modified, void* stream);
 /* columns scaled to unit 2-norm (normalize, :52-63) */

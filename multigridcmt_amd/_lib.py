@@ -92,6 +92,10 @@ _SIGNATURES = {
     "mgcmt_rayleigh_residual": (c_int, [c_void_p, c_int, c_int, c_int, _dp, _dp, c_void_p]),
     "mgcmt_lincomb": (c_int, [c_void_p, c_int, c_int, _dp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_void_p]),
     "mgcmt_scale": (c_int, [c_void_p, c_int, c_double, c_int, c_int, c_void_p]),
+    "mgcmt_block_gram": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int), c_int, POINTER(c_int), POINTER(c_int),
+                                 POINTER(c_double), c_void_p]),
+    "mgcmt_block_combine": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int), c_int, POINTER(c_int), POINTER(c_int),
+                                    POINTER(c_double), c_void_p]),
     "mgcmt_gramschmidt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mgcmt_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "mgcmt_fused_pass": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p]),

@@ -294,6 +294,74 @@ __global__ void k_lincomb(long n, LincombArgs a, int nt, double* dst) {
   }
 }
 
+// Block operations of the blocked Rayleigh-Ritz eigen-solver (drivers.block_eigensolve; SURVEY par. 8(f)4: the "blocked,
+// LOBPCG-style updates" for the reference's Rayleigh-quotient routines, MGCMTSolver.py:44-50 carried from 2 to 3k trial
+// vectors): the cross Gram matrix A^T B of up to 12 x 4 vectors in ONE pass (every vector read once), and the
+// tall-skinny product OUT = IN C (up to 12 inputs, 4 outputs) with every input read once.  Deterministic: fixed per-thread
+// order, fixed tree.
+struct BlockGramArgs {
+  const double* a[kBlockMaxA];
+  const double* b[kBlockMaxB];
+};
+__global__ void __launch_bounds__(kRedThreads) k_block_gram(long n, BlockGramArgs g, int na, int nb, double* __restrict__ partials) {
+  constexpr int kWaves = kRedThreads / 64;
+  constexpr int kPairs = kBlockMaxA * kBlockMaxB;
+  __shared__ double s_part[kWaves][kPairs];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc[kPairs];
+#pragma unroll
+  for (int t = 0; t < kPairs; ++t) acc[t] = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double y[kBlockMaxB];
+#pragma unroll
+    for (int b = 0; b < kBlockMaxB; ++b) y[b] = b < nb ? g.b[b][i] : 0.0;
+#pragma unroll
+    for (int a = 0; a < kBlockMaxA; ++a) {
+      if (a < na) {  // (wave-uniform)
+        const double x = g.a[a][i];
+#pragma unroll
+        for (int b = 0; b < kBlockMaxB; ++b) acc[a * kBlockMaxB + b] = fma(x, y[b], acc[a * kBlockMaxB + b]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kPairs; ++t) {
+    const double tot = wave_sum(acc[t]);
+    if (lane == 0) s_part[wave][t] = tot;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < kPairs) {
+    double tot = 0.0;
+    for (int w = 0; w < kWaves; ++w) tot += s_part[w][threadIdx.x];
+    partials[(long)threadIdx.x * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
+struct BlockCombineArgs {
+  const double* in[kBlockMaxA];
+  double* out[kBlockMaxB];
+  double c[kBlockMaxA][kBlockMaxB];
+};
+// (an output may be one of the inputs: a thread reads all inputs of an element before it writes any output of it)
+__global__ void k_block_combine(long n, BlockCombineArgs a, int nin, int nout) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double acc[kBlockMaxB];
+#pragma unroll
+    for (int j = 0; j < kBlockMaxB; ++j) acc[j] = 0.0;
+#pragma unroll
+    for (int t = 0; t < kBlockMaxA; ++t) {
+      if (t < nin) {
+        const double x = a.in[t][i];
+#pragma unroll
+        for (int j = 0; j < kBlockMaxB; ++j) acc[j] = fma(a.c[t][j], x, acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kBlockMaxB; ++j)
+      if (j < nout) a.out[j][i] = acc[j];
+  }
+}
+
 // bandwidth probes (bench.py's empirical HBM ceilings): 16-byte accesses, grid-stride
 __global__ void k_probe_copy(long n2, const double2* __restrict__ a, double2* __restrict__ out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) out[i] = a[i];
@@ -421,6 +489,27 @@ void launch_lincomb(hipStream_t s, long n, const double* const* v, const double*
     a.c[t] = t < nt ? c[t] : 0.0;
   }
   hipLaunchKernelGGL(k_lincomb, dim3(blocks_for(n)), dim3(256), 0, s, n, a, nt, dst);
+}
+
+// out[a * kBlockMaxB + b] (device) = <A_a, B_b>
+void launch_block_gram(hipStream_t s, long n, const double* const* a, int na, const double* const* b, int nb, double* partials, double* out) {
+  BlockGramArgs g{};
+  for (int t = 0; t < kBlockMaxA; ++t) g.a[t] = a[t < na ? t : 0];
+  for (int t = 0; t < kBlockMaxB; ++t) g.b[t] = b[t < nb ? t : 0];
+  const int blocks = reduce_blocks(n);
+  hipLaunchKernelGGL(k_block_gram, dim3(blocks), dim3(kRedThreads), 0, s, n, g, na, nb, partials);
+  hipLaunchKernelGGL(k_dot_final, dim3(kBlockMaxA * kBlockMaxB), dim3(kRedThreads), 0, s, blocks, partials, out);
+}
+
+// out_j = sum_t c[t * nout + j] in_t
+void launch_block_combine(hipStream_t s, long n, const double* const* in, int nin, double* const* out, int nout, const double* c) {
+  BlockCombineArgs a{};
+  for (int t = 0; t < kBlockMaxA; ++t) {
+    a.in[t] = in[t < nin ? t : 0];
+    for (int j = 0; j < kBlockMaxB; ++j) a.c[t][j] = (t < nin && j < nout) ? c[t * nout + j] : 0.0;
+  }
+  for (int j = 0; j < kBlockMaxB; ++j) a.out[j] = out[j < nout ? j : 0];
+  hipLaunchKernelGGL(k_block_combine, dim3(blocks_for(n)), dim3(256), 0, s, n, a, nin, nout);
 }
 
 bool mgs_small_fits(long n) { return n <= kMgsSmallMaxN; }

@@ -112,6 +112,9 @@ void launch_dot_partials(hipStream_t s, long n, const double* x, const double* y
 void launch_scale_by_norm(hipStream_t s, long n, const double* partials, double* x);
 void launch_project_out(hipStream_t s, long n, const double* partials, const double* q, double* a_first, long astride, int nj);
 constexpr int kGramMaxVectors = 6;
+constexpr int kBlockMaxA = 12, kBlockMaxB = 4;  // block operations: up to 12 x 4 vectors (three blocks of four trial vectors)
+void launch_block_gram(hipStream_t s, long n, const double* const* a, int na, const double* const* b, int nb, double* partials, double* out);
+void launch_block_combine(hipStream_t s, long n, const double* const* in, int nin, double* const* out, int nout, const double* c);
 void launch_gram(hipStream_t s, long n, const double* const* v, int nv, double* partials, double* out);
 void launch_lincomb(hipStream_t s, long n, const double* const* v, const double* c, int nt, double* dst);
 bool mgs_small_fits(long n);

@@ -1112,6 +1112,55 @@ int mgcmt_lincomb(mgcmt_plan* p, int l, int nterms, const double* coeffs, const 
   return post_launch();
 }
 
+int mgcmt_block_gram(mgcmt_plan* p, int l, int na, const int* a_slots, const int* a_vecs, int nb, const int* b_slots, const int* b_vecs,
+                     double* host_out, void* stream) {
+  MG_TRY(check_level(p, l));
+  if (!a_slots || !a_vecs || !b_slots || !b_vecs || !host_out || na < 1 || na > kBlockMaxA || nb < 1 || nb > kBlockMaxB)
+    return fail(MGCMT_ERR_INVALID, "block_gram: 1..12 by 1..4 vectors, non-null arguments");
+  const double *a[kBlockMaxA], *b[kBlockMaxB];
+  for (int t = 0; t < na; ++t) {
+    MG_TRY(check_vec(p, l, a_slots[t], a_vecs[t]));
+    MG_TRY(ensure_slot(p, l, a_slots[t]));
+    a[t] = p->kvec(l, a_slots[t], a_vecs[t]).p;
+  }
+  for (int t = 0; t < nb; ++t) {
+    MG_TRY(check_vec(p, l, b_slots[t], b_vecs[t]));
+    MG_TRY(ensure_slot(p, l, b_slots[t]));
+    b[t] = p->kvec(l, b_slots[t], b_vecs[t]).p;
+  }
+  launch_block_gram(S(stream), p->interior(l), a, na, b, nb, p->d_partials, p->d_scalars);
+  MG_TRY(post_launch());
+  double packed[kBlockMaxA * kBlockMaxB];
+  MG_HIP(hipMemcpyAsync(packed, p->d_scalars, sizeof(packed), hipMemcpyDeviceToHost, S(stream)));
+  MG_HIP(hipStreamSynchronize(S(stream)));
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j) host_out[i * nb + j] = packed[i * kBlockMaxB + j];
+  return MGCMT_OK;
+}
+
+int mgcmt_block_combine(mgcmt_plan* p, int l, int nin, const int* in_slots, const int* in_vecs, int nout, const int* out_slots,
+                        const int* out_vecs, const double* coeffs, void* stream) {
+  MG_TRY(check_level(p, l));
+  if (!in_slots || !in_vecs || !out_slots || !out_vecs || !coeffs || nin < 1 || nin > kBlockMaxA || nout < 1 || nout > kBlockMaxB)
+    return fail(MGCMT_ERR_INVALID, "block_combine: 1..12 inputs, 1..4 outputs, non-null arguments");
+  const double* in[kBlockMaxA];
+  double* out[kBlockMaxB];
+  for (int t = 0; t < nin; ++t) {
+    MG_TRY(check_vec(p, l, in_slots[t], in_vecs[t]));
+    MG_TRY(ensure_slot(p, l, in_slots[t]));
+    in[t] = p->kvec(l, in_slots[t], in_vecs[t]).p;
+  }
+  for (int j = 0; j < nout; ++j) {
+    MG_TRY(check_vec(p, l, out_slots[j], out_vecs[j]));
+    MG_TRY(ensure_slot(p, l, out_slots[j]));
+    out[j] = p->kvec(l, out_slots[j], out_vecs[j]).p;
+    for (int i = 0; i < j; ++i)
+      if (out[i] == out[j]) return fail(MGCMT_ERR_INVALID, "block_combine: an output vector named twice");
+  }
+  launch_block_combine(S(stream), p->interior(l), in, nin, out, nout, coeffs);
+  return post_launch();
+}
+
 int mgcmt_axpy(mgcmt_plan* p, int l, double alpha, int x_slot, int x_vec, int y_slot, int y_vec, void* stream) {
   MG_TRY(check_vec(p, l, x_slot, x_vec));
   MG_TRY(check_vec(p, l, y_slot, y_vec));

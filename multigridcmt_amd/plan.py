@@ -181,6 +181,25 @@ class Plan:
         vecs = (ctypes.c_int * nt)(*[v[1] for _, v in terms])
         check(_lib.lib().mgcmt_lincomb(self._h, level, nt, _lib.as_dp(coeffs), slots, vecs, dst[0], dst[1], stream))
 
+    def block_gram(self, level, a, b, stream=None):
+        """A^T B for lists of (slot, vec) pairs, len(a) <= 12, len(b) <= 4, in one pass; synchronises."""
+        na, nb = len(a), len(b)
+        out = np.zeros((na, nb))
+        check(_lib.lib().mgcmt_block_gram(self._h, level, na, (ctypes.c_int * na)(*[v[0] for v in a]), (ctypes.c_int * na)(*[v[1] for v in a]),
+                                          nb, (ctypes.c_int * nb)(*[v[0] for v in b]), (ctypes.c_int * nb)(*[v[1] for v in b]),
+                                          _lib.as_dp(out), stream))
+        return out
+
+    def block_combine(self, level, inputs, outputs, coeffs, stream=None):
+        """outputs[j] <- sum_i coeffs[i, j] * inputs[i] ((slot, vec) pairs; <= 12 inputs, <= 4 distinct outputs; an output
+        may be one of the inputs)."""
+        nin, nout = len(inputs), len(outputs)
+        c = np.ascontiguousarray(np.asarray(coeffs, dtype=np.float64).reshape(nin, nout))
+        check(_lib.lib().mgcmt_block_combine(self._h, level, nin, (ctypes.c_int * nin)(*[v[0] for v in inputs]),
+                                             (ctypes.c_int * nin)(*[v[1] for v in inputs]), nout,
+                                             (ctypes.c_int * nout)(*[v[0] for v in outputs]), (ctypes.c_int * nout)(*[v[1] for v in outputs]),
+                                             _lib.as_dp(c), stream))
+
     def axpy(self, level, alpha, x, y, stream=None):
         check(_lib.lib().mgcmt_axpy(self._h, level, c_double(alpha), x[0], x[1], y[0], y[1], stream))
 

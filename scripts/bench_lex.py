@@ -6,6 +6,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from multigridcmt_amd import _lib
+if os.environ.get("MGCMT_LIB"):
+    _lib.use_library(os.environ["MGCMT_LIB"])
 from multigridcmt_amd.operators import laplacian_operator
 from multigridcmt_amd.plan import Plan
 
@@ -16,9 +18,9 @@ def timed(p, fn, n):
     p.sync(); return round((time.perf_counter() - t0) / n * 1e3, 3)
 
 
-for g in (512, 1024, 4096, 16384):
+for g in [int(x) for x in os.environ.get("LEX_GRIDS", "512,1024,4096,16384").split(",")]:
     row = {"grid": g}
-    for wave in (2, 1, 0):
+    for wave in [int(x) for x in os.environ.get("LEX_MODES", "2,1,0").split(",")]:
         if wave == 0 and g > 4096:
             continue
         p = Plan(laplacian_operator(g, "2d") * (-1 / np.pi ** 2), 8, nvec=1)

@@ -6,5 +6,5 @@ build() { name=$1; shift; make -s -j8 OUT=$PWD/../../variants/lib_$name.so OBJDI
 build depth9_3 EXTRA=-DMGCMT_FUSED_DEPTH9=3
 # diagnostic build of the lexicographic wave pipeline (per-block timing words; scripts/lex_debug.py)
 build lexdebug EXTRA=-DMGCMT_LEXWAVE_DEBUG
-# chained lexicographic sweeps with records asked for 4 rows ahead (default 7): diagnosis of a visibility race
-build chainrec4 EXTRA=-DMGCMT_LEX_CHAIN_REC=4
+# chained lexicographic sweeps: records asked for 6 rows ahead (default 4; must stay below the old values' distance)
+build chainrec6 EXTRA=-DMGCMT_LEX_CHAIN_REC=6

@@ -173,3 +173,36 @@ def test_operator_mutated_in_place_between_calls(backend):
         x = solver.vcycle(np.zeros(g * g), f.copy(), A, sm, nu1=2, nu2=2, shift=0.3, dimension="2d", lowest_level=8)
         y = ref.vcycle(np.zeros(g * g), f, A.copy(), rsm, nu1=2, nu2=2, shift=0.3, dimension="2d", lowest_level=8)
         assert rel_err(x, y) < 1e-11, factor
+
+
+def test_block_gram_and_combine(backend):
+    """mgcmt_block_gram / mgcmt_block_combine against numpy: up to 12 x 4 vectors, outputs aliasing inputs, bad arguments."""
+    from multigridcmt_amd import _lib
+    from multigridcmt_amd.operators import laplacian_operator
+    from multigridcmt_amd.plan import Plan
+    from multigridcmt_amd._lib import MgcmtError
+    g, nv = 32, 12
+    p = Plan(laplacian_operator(g, "2d"), 4, nvec=nv)
+    rng = np.random.RandomState(2)
+    host = {}
+    for slot in (_lib.SLOT_W, _lib.SLOT_F):
+        for j in range(nv):
+            host[(slot, j)] = rng.randn(g * g)
+            p.upload(0, slot, j, host[(slot, j)])
+    A = [(_lib.SLOT_W, j) for j in range(12)]
+    B = [(_lib.SLOT_F, j) for j in (3, 0, 7, 11)]
+    G = p.block_gram(0, A, B)
+    want = np.array([[host[a] @ host[b] for b in B] for a in A])
+    assert np.allclose(G, want, rtol=1e-13, atol=1e-11)
+    assert np.allclose(p.block_gram(0, A[:5], A[:3]), np.array([[host[a] @ host[b] for b in A[:3]] for a in A[:5]]), rtol=1e-13, atol=1e-11)
+    C = rng.randn(7, 3)
+    ins = A[:4] + B[:3]
+    outs = [A[1], B[0], (_lib.SLOT_F, 5)]                   # two of the outputs are inputs
+    p.block_combine(0, ins, outs, C)
+    for j, o in enumerate(outs):
+        assert np.allclose(p.download(0, o[0], o[1]), sum(C[i, j] * host[v] for i, v in enumerate(ins)), rtol=1e-13, atol=1e-12)
+    with pytest.raises(MgcmtError):
+        p.block_combine(0, ins, [A[1], A[1]], np.zeros((7, 2)))   # an output named twice
+    with pytest.raises(MgcmtError):
+        p.block_gram(0, A + [A[0]], B)                              # 13 vectors
+    p.close()
