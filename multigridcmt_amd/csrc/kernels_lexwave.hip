@@ -343,6 +343,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   //     never reads a value right of the grid that the masks do not cover: garbage there stays there);
   //   - the last column of a 9-point level (its own diagonal and N / S coefficients, its own q) is patched AFTER the
   //     regular scan: x_lc = pc + qcol x_(lc - 1) with pc from p by the ratio of the two diagonals.
+  const int lc_lo = J * 64 - (nc - 1);  // rows lc_lo .. lc_lo + 63 hold the last column in their window
   const double rho = inv_col * d_int;  // (k..c = rho k.. for every term whose coefficient the last column shares)
   const double dS = kSc - rho * kS, dN = kNc - rho * kN, dO = kOc - rho * kO;
   auto row_body = [&](auto ph, auto interior, int i, double& x, double& c1, double& c2) __attribute__((always_inline)) {
@@ -403,8 +404,11 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
           p = fma(kNE, ne, p);
         }
         double pc = 0.0;
-        const bool has_last_col = !FIVE && J * 64 - i <= nc - 1 && J * 64 - i + 63 >= nc - 1;  // (wave-uniform)
-        if (has_last_col) pc = fma(dO, own, fma(dN, n, fma(dS, s, rho * p)));
+        const bool has_last_col = !FIVE && (unsigned)(i - lc_lo) <= 63u;  // the window holds column nc - 1 (wave-uniform)
+        if (has_last_col) {
+          pc = fma(dN, n, fma(dS, s, rho * p));
+          if (OWN) pc = fma(dO, own, pc);
+        }
         if (!valid) p = 0.0;
         p = fma(q0, row_shr<1>(p, lane), p);
         p = fma(q2, row_shr<2>(p, lane), p);
@@ -603,16 +607,18 @@ void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.progress = a.carry + (long)a.nsweeps * a.sweep_stride;
   (void)hipMemsetAsync(sync, 0, sizeof(unsigned) * 2, s);
   (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * ((size_t)a.nsweeps * a.sweep_stride + (size_t)a.nsweeps * k * a.nblocks), s);
-  const bool five = op.five_point, own = alpha != 0.0 || gamma != 0.0 || !five;
+  const bool five = op.five_point, own = alpha != 0.0 || gamma != 0.0;
   if (a.nsweeps > 1) {
     const dim3 grid((unsigned)((a.nblocks + 2 * (a.nsweeps - 1)) * a.nsweeps * k));
     if (five && !own) hipLaunchKernelGGL((k_lex_wave<true, false, true>), grid, dim3(64), 0, s, a);
     else if (five) hipLaunchKernelGGL((k_lex_wave<true, true, true>), grid, dim3(64), 0, s, a);
+    else if (!own) hipLaunchKernelGGL((k_lex_wave<false, false, true>), grid, dim3(64), 0, s, a);
     else hipLaunchKernelGGL((k_lex_wave<false, true, true>), grid, dim3(64), 0, s, a);
   } else {
     const dim3 grid((unsigned)(a.nblocks * k));
     if (five && !own) hipLaunchKernelGGL((k_lex_wave<true, false, false>), grid, dim3(64), 0, s, a);
     else if (five) hipLaunchKernelGGL((k_lex_wave<true, true, false>), grid, dim3(64), 0, s, a);
+    else if (!own) hipLaunchKernelGGL((k_lex_wave<false, false, false>), grid, dim3(64), 0, s, a);
     else hipLaunchKernelGGL((k_lex_wave<false, true, false>), grid, dim3(64), 0, s, a);
   }
 }

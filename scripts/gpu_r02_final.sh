@@ -14,5 +14,6 @@ timeout -k 10 300 python bench.py --smoother rb --steps 20 --warmup 5 --no-cpu-b
 timeout -k 10 300 python bench.py --config 1 --steps 40 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_cfg2.json 2>/dev/null
 timeout -k 10 300 python scripts/bench_config5.py > gpurun_out/${TAG}_bench_cfg5.json 2>/dev/null
 timeout -k 10 300 python scripts/bench_python_call.py > gpurun_out/${TAG}_pycall.log 2>&1
+timeout -k 10 400 python scripts/bench_lex.py > gpurun_out/${TAG}_bench_lex.log 2>&1
 bash scripts/gpu_r02_profiles.sh $TAG > gpurun_out/${TAG}_profiles.log 2>&1
 tail -12 gpurun_out/${TAG}_profiles.log
