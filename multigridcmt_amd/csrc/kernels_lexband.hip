@@ -344,7 +344,7 @@ void launch_lex_band(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.sync = sync;
   a.band_stride = lex_band_stride(g);
   a.carry_stride = a.band_stride * a.nbands;
-  (void)hipMemsetAsync(sync, 0, sizeof(unsigned) * 2, s);
+  (void)hipMemsetAsync(sync, 0, sizeof(unsigned), s);  // (the ticket; the error word stays until the host has looked)
   (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * (size_t)k * a.carry_stride, s);
   const dim3 grid((unsigned)(a.nbands * k));
   if (op.five_point && alpha == 0.0) hipLaunchKernelGGL((k_lex_band<true, false>), grid, dim3(64), 0, s, a);

@@ -46,7 +46,8 @@ struct LexWaveArgs {
   double alpha, beta, wU, wL;
   double gamma;               // what is stored is x + gamma f (x goes on down the recurrence): reference SOR's v += w (D-L)^-1 f in the sweep
   unsigned long long* carry;  // [sweep][vector][block][row][4] granules {tag = 1 : 32, half of a double : 32}: lanes 62 / 63's new values
-  unsigned* sync;             // [0] ticket, [1] error
+  unsigned* sync;             // [1] error word (set by a block that gave up; cleared by the host when it reports it), [2..] diagnostics
+  unsigned* ticket;           // block numbers (the first word of the scratch buffer: cleared with it, ONE memset per launch)
   long carry_stride;          // granules per vector
   int nsweeps;                // sweeps chained in this launch (1: the plain sweep)
   int nvec;                   // vectors in this launch
@@ -56,6 +57,9 @@ struct LexWaveArgs {
 };
 
 constexpr int kTerminalRows = 16;  // (spare rows behind a block's records: the record prefetch runs a few rows past the last one)
+#ifndef MGCMT_LEX_REC
+#define MGCMT_LEX_REC 4  // rows ahead at which the left block's records are asked for (tuning)
+#endif
 #ifndef MGCMT_LEX_CHAIN_REC
 #define MGCMT_LEX_CHAIN_REC 4  // chained sweeps: rows ahead at which records are asked for (tuning)
 #endif
@@ -80,7 +84,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   const int lane = threadIdx.x;
   // block number = order of arrival: whoever this block waits for has started before it
   unsigned ticket = 0;
-  if (lane == 0) ticket = atomicAdd(&a.sync[0], 1u);
+  if (lane == 0) ticket = atomicAdd(a.ticket, 1u);
   ticket = (unsigned)uniform(__shfl((int)ticket, 0));
   const int nsw = CH ? a.nsweeps : 1;
   const int per_vector = CH ? (a.nblocks + 2 * (nsw - 1)) * nsw : a.nblocks;  // (chained: some numbers stand for no block)
@@ -145,7 +149,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // sum of those lags over the blocks is the sweep's start-up time.  A step issues [row store, record store, record load of
   // row i + kRec, old values of row i + kDepth + 1]; loads complete in order, so the wait of step i — for the record of row
   // i, issued kRec steps ago — lets only what was issued after it stay in flight.
-  constexpr int kRec = CH ? MGCMT_LEX_CHAIN_REC : 4;  // (chained sweeps load v past the caches: the longer latency wants more steps between a load and the wait behind it)
+  constexpr int kRec = CH ? MGCMT_LEX_CHAIN_REC : MGCMT_LEX_REC;  // (chained sweeps load v past the caches: the longer latency wants more steps between a load and the wait behind it)
   constexpr int kProgressTrips = 3;                   // chained sweeps: trips (of kSlots rows) between two publications of a block's progress
   constexpr int kWaitN = (kLoads - 1) + (kRec - 1) * kOps;
   static_assert(kWaitN <= 63, "vmcnt is a 6-bit counter");
@@ -239,13 +243,10 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   auto unpack = [&](u64 R, double& c1, double& c2) __attribute__((always_inline)) {  // false: the record is not complete yet
     const unsigned lo = (unsigned)R, hi = (unsigned)(R >> 32);  // (the register's two halves: half a double, the tag)
     c1 = __builtin_bit_cast(double, (u64)lane_word(lo, 2) | ((u64)lane_word(lo, 3) << 32));  // the left block's lane 63
-    unsigned tags = lane_word(hi, 2) & lane_word(hi, 3);
     c2 = 0.0;
-    if (!FIVE) {
-      c2 = __builtin_bit_cast(double, (u64)lane_word(lo, 0) | ((u64)lane_word(lo, 1) << 32));  // ... lane 62
-      tags &= lane_word(hi, 0) & lane_word(hi, 1);
-    }
-    return tags == 1u;
+    if (!FIVE) c2 = __builtin_bit_cast(double, (u64)lane_word(lo, 0) | ((u64)lane_word(lo, 1) << 32));  // ... lane 62
+    const u64 need = FIVE ? 0xCull : 0xFull;  // the tags of granules 2, 3 (and 0, 1): one compare, one vote
+    return (vote_eq(hi, 1u) & need) == need;
   };
   auto wait_record = [&](int row, double& c1, double& c2) __attribute__((always_inline)) {  // the slow path: ask until the record is complete
 #ifdef MGCMT_LEXWAVE_DEBUG
@@ -488,9 +489,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
       if (valid) store_value<CH>(vst + lane8, OWN ? fma(gamma, fv, x) : x);
     }
     {  // the row's edge record: {tag, half a double} granules, ONE store instruction (lanes 60..63; FIVE: 62, 63)
-      const double t1 = from_right(x, lane);   // lane 62: x63, lane 61: x62
-      const double t2 = from_right(t1, lane);  // lane 60: x62
-      const double src = lane == 63 ? x : (lane == 60 ? t2 : t1);
+      const double src = quad_pairs(x, lane);  // lanes 60, 61: x62; lanes 62, 63: x63
       const u64 bits = __builtin_bit_cast(u64, src);
       const u64 word = (1ull << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xffffffffull));
       if (lane >= (FIVE ? 62 : 60)) store_granule(reinterpret_cast<u64*>(rst + lane8), word);
@@ -559,10 +558,10 @@ bool lex_wave_supported(const KGrid& g, const KOp& op) {
 
 long lex_wave_blocks(const KGrid& g) { return (g.nr + g.nc - 1 + 63) / 64; }
 
-// scratch: carry = nsweeps * k * blocks * (nr + kTerminalRows) * 4 granules of 8 bytes (cleared here: a record is valid when
-// its tags are set), sync = 2 words (cleared here).  nsweeps > 1: that many sweeps chained in ONE launch (see k_lex_wave)
+// scratch: carry = lex_wave_carry() granules of 8 bytes (cleared here: the ticket, the records — valid when their tags are
+// set —, the progress words), sync = the error word and the diagnostic build's words (not cleared here).  nsweeps > 1: that many sweeps chained in ONE launch (see k_lex_wave)
 long lex_wave_carry(const KGrid& g, int k, int nsweeps) {
-  return (long)nsweeps * k * lex_wave_blocks(g) * ((g.nr + kTerminalRows) * 4 + 1) + 64;  // (records + one progress word per block)
+  return 8 + (long)nsweeps * k * lex_wave_blocks(g) * ((g.nr + kTerminalRows) * 4 + 1) + 64;  // (ticket, records, one progress word per block)
 }
 
 void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double alpha, double beta, double wU,
@@ -597,7 +596,8 @@ void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.wU = wU;
   a.wL = wL;
   a.gamma = gamma;
-  a.carry = reinterpret_cast<unsigned long long*>(carry);
+  a.ticket = reinterpret_cast<unsigned*>(carry);
+  a.carry = reinterpret_cast<unsigned long long*>(carry) + 8;
   a.sync = sync;
   a.nsweeps = nsweeps < 1 ? 1 : nsweeps;
   a.rec_rows = (int)g.nr + kTerminalRows;
@@ -605,8 +605,9 @@ void launch_lex_wave(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
   a.sweep_stride = a.carry_stride * k;
   a.nvec = k;
   a.progress = a.carry + (long)a.nsweeps * a.sweep_stride;
-  (void)hipMemsetAsync(sync, 0, sizeof(unsigned) * 2, s);
-  (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * ((size_t)a.nsweeps * a.sweep_stride + (size_t)a.nsweeps * k * a.nblocks), s);
+  // ONE memset: the ticket, the records, the progress words.  (The error word is not touched: a launch must not wipe out
+  // what an earlier one reported before the host has looked.)
+  (void)hipMemsetAsync(carry, 0, sizeof(unsigned long long) * (8 + (size_t)a.nsweeps * a.sweep_stride + (size_t)a.nsweeps * k * a.nblocks), s);
   const bool five = op.five_point, own = alpha != 0.0 || gamma != 0.0;
   if (a.nsweeps > 1) {
     const dim3 grid((unsigned)((a.nblocks + 2 * (a.nsweeps - 1)) * a.nsweeps * k));

@@ -97,6 +97,7 @@ template <int D>
 __device__ __forceinline__ double row_shr(double v, int) { return dpp<0x110 + D>(v); }    // lane - D inside rows of 16 (else 0)
 __device__ __forceinline__ double bcast15(double v, int) { return dpp<0x142>(v); }         // lane 15 of the previous row of 16
 __device__ __forceinline__ double bcast31(double v, int) { return dpp<0x143>(v); }         // lane 31
+__device__ __forceinline__ double quad_pairs(double v, int) { return dpp<0xFA>(v); }      // lanes 4k..4k+3 <- lanes 4k+2, 4k+2, 4k+3, 4k+3
 __device__ __forceinline__ double from_left(double v, int) { return dpp<0x138>(v); }       // lane - 1 (lane 0: 0)
 __device__ __forceinline__ double from_right(double v, int) { return dpp<0x130>(v); }      // lane + 1 (lane 63: 0)
 __device__ __forceinline__ u64 lane_bits(u64 u, int k) {
@@ -106,6 +107,7 @@ __device__ __forceinline__ u64 lane_bits(u64 u, int k) {
 }
 __device__ __forceinline__ unsigned lane_word(unsigned x, int k) { return (unsigned)__builtin_amdgcn_readlane((int)x, k); }
 __device__ __forceinline__ u64 vote(bool x) { return __ballot(x); }
+__device__ __forceinline__ u64 vote_eq(unsigned a, unsigned b) { return __builtin_amdgcn_uicmp(a, b, 32 /* ICMP_EQ */); }  // lanes with a == b
 __device__ __forceinline__ unsigned load_word(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_word(unsigned* p, unsigned x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 load_granule(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -129,6 +131,7 @@ template <int D>
 __device__ __forceinline__ double row_shr(double v, int lane) { const double r = __shfl_up(v, D); return (lane & 15) >= D ? r : 0.0; }
 __device__ __forceinline__ double bcast15(double v, int lane) { return __shfl(v, ((lane & ~15) - 1) & 63); }
 __device__ __forceinline__ double bcast31(double v, int) { return __shfl(v, 31); }
+__device__ __forceinline__ double quad_pairs(double v, int lane) { return __shfl(v, (lane & ~3) + 2 + ((lane & 3) >> 1)); }
 __device__ __forceinline__ double from_left(double v, int lane) { const double r = __shfl_up(v, 1); return lane >= 1 ? r : 0.0; }
 __device__ __forceinline__ double from_right(double v, int lane) { const double r = __shfl_down(v, 1); return lane <= 62 ? r : 0.0; }
 __device__ __forceinline__ u64 lane_bits(u64 u, int k) { return (u64)__shfl((long long)u, k); }
@@ -138,6 +141,7 @@ __device__ __forceinline__ u64 vote(bool x) {
   for (int k = 0; k < 64; ++k) m |= (u64)(__shfl(x ? 1 : 0, k) & 1) << k;
   return m;
 }
+__device__ __forceinline__ u64 vote_eq(unsigned a, unsigned b) { return vote(a == b); }
 __device__ __forceinline__ unsigned load_word(const unsigned* p) { return *p; }
 __device__ __forceinline__ void store_word(unsigned* p, unsigned x) { *p = x; }
 __device__ __forceinline__ u64 load_granule(const u64* p) { return *p; }

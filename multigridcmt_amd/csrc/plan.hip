@@ -301,6 +301,7 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
       if (hipMalloc((void**)&p->lex_carry, need_carry * sizeof(double)) != hipSuccess ||
           hipMalloc((void**)&p->lex_sync, need_sync * sizeof(unsigned)) != hipSuccess)
         return fail(MGCMT_ERR_NOMEM, "scratch of the lexicographic wave pipeline");
+      MG_HIP(hipMemset(p->lex_sync, 0, need_sync * sizeof(unsigned)));
       p->lex_carry_doubles = need_carry;
       p->lex_sync_words = need_sync;
     }
@@ -331,7 +332,10 @@ int lex_wave_check(mgcmt_plan* p) {
   p->lex_wave_used = false;
   unsigned err = 0;
   MG_HIP(hipMemcpy(&err, p->lex_sync + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
-  if (err != 0) return fail(MGCMT_ERR_HIP, "lexicographic wave pipeline: a block timed out waiting for its neighbour");
+  if (err != 0) {
+    MG_HIP(hipMemset(p->lex_sync + 1, 0, sizeof(unsigned)));  // reported: the next sweeps start clean
+    return fail(MGCMT_ERR_HIP, "lexicographic wave pipeline: a block timed out waiting for its neighbour");
+  }
   return MGCMT_OK;
 }
 
