@@ -294,7 +294,10 @@ int mgcmt_lex_wave_stats(mgcmt_plan* plan, uint32_t* out, int64_t capacity);
  * the fused kernels' access pattern instead (128-column windows marching down `blocks` rows): read 1 stream (8 B),
  * read 2 (16 B), read 2 + write 1 (24 B); kinds 6/7/8 the same with overlapping, unaligned windows (124 of 128 kept),
  * 9/10/11 with the fused kernels' own geometry (112 of 128 kept: line-aligned stores, loads straddling half lines),
- * 12/13/14 with 96 of 128 kept (everything line-aligned), 15/16/17 with 120 of 128 (64-byte-aligned); returns the average milliseconds per launch */
+ * 12/13/14 with 96 of 128 kept (everything line-aligned), 15/16/17 with 120 of 128 (64-byte-aligned); kinds 20..23 are
+ * issue-rate probes — `blocks` workgroups of ONE wave each run 20000 trips of 64 instructions: a chain of dependent double
+ * FMAs (20), eight independent chains (21), dependent 32-bit vector adds (22), dependent scalar adds (23); returns the
+ * average milliseconds per launch */
 int mgcmt_bandwidth_probe(mgcmt_plan* plan, int level, int kind, int blocks, int reps, double* ms_out, void* stream);
 
 #ifdef __cplusplus

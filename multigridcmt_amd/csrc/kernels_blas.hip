@@ -446,6 +446,50 @@ void launch_probe_march(hipStream_t s, long nr, long nc, long rows, int nstreams
   hipLaunchKernelGGL(k_probe_march, dim3((unsigned)(strips * chunks)), dim3(64), 0, s, nr, nc, rows, nstreams, do_write, wout, a, b, out, out);
 }
 
+// issue-rate probes: ONE wave per workgroup runs `iters` trips of 64 instructions — a chain of dependent double FMAs (0), eight
+// independent chains of them (1), a chain of dependent 32-bit integer adds (2), independent scalar adds (3): what a single
+// wave can issue is what bounds the lexicographic pipelines (DESIGN.md par. 4.3)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MGCMT_PROBE_VADD(k) asm volatile("v_add_u32 %0, %0, 3" : "+v"(k))
+#define MGCMT_PROBE_SADD(k) asm volatile("s_add_u32 %0, %0, 3" : "+s"(k))
+#else
+#define MGCMT_PROBE_VADD(k) (k) += 3
+#define MGCMT_PROBE_SADD(k) (k) += 3
+#endif
+__global__ void __launch_bounds__(64) k_probe_issue(int what, int iters, double* sink) {
+  double x[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) x[t] = 1.0 + 1e-9 * (threadIdx.x + t);
+  const double m = 1.0 - 1e-12, c = 1e-13;
+  int k = threadIdx.x;
+  int sacc = iters;
+  for (int it = 0; it < iters; ++it) {
+    if (what == 0) {
+#pragma unroll
+      for (int u = 0; u < 64; ++u) x[0] = fma(x[0], m, c);
+    } else if (what == 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = fma(x[t], m, c);
+    } else if (what == 2) {
+#pragma unroll
+      for (int u = 0; u < 64; ++u) MGCMT_PROBE_VADD(k);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 64; ++u) MGCMT_PROBE_SADD(sacc);
+    }
+  }
+  double t = 0.0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) t += x[u];
+  if (t == 123.456) sink[0] = t + k + sacc;  // (never true: keeps the work alive)
+}
+
+void launch_probe_issue(hipStream_t s, int what, int iters, int blocks, double* sink) {
+  hipLaunchKernelGGL(k_probe_issue, dim3(blocks), dim3(64), 0, s, what, iters, sink);
+}
+
 void launch_probe(hipStream_t s, int kind, long n, const double* a, const double* b, double* out, int blocks) {
   const long n2 = n / 2;
   if (kind == 0) hipLaunchKernelGGL(k_probe_copy, dim3(blocks), dim3(256), 0, s, n2, (const double2*)a, (double2*)out);

@@ -113,6 +113,7 @@ void launch_scale_by_norm(hipStream_t s, long n, const double* partials, double*
 void launch_project_out(hipStream_t s, long n, const double* partials, const double* q, double* a_first, long astride, int nj);
 constexpr int kGramMaxVectors = 6;
 constexpr int kBlockMaxA = 12, kBlockMaxB = 4;  // block operations: up to 12 x 4 vectors (three blocks of four trial vectors)
+void launch_probe_issue(hipStream_t s, int what, int iters, int blocks, double* sink);  // kinds 20..23 of mgcmt_bandwidth_probe
 void launch_block_gram(hipStream_t s, long n, const double* const* a, int na, const double* const* b, int nb, double* partials, double* out);
 void launch_block_combine(hipStream_t s, long n, const double* const* in, int nin, double* const* out, int nout, const double* c);
 void launch_gram(hipStream_t s, long n, const double* const* v, int nv, double* partials, double* out);

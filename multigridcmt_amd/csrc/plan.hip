@@ -1303,7 +1303,7 @@ int mgcmt_time_smoother(mgcmt_plan* p, int l, int kind, int nu, double omega, in
 
 int mgcmt_bandwidth_probe(mgcmt_plan* p, int l, int kind, int blocks, int reps, double* ms_out, void* stream) {
   MG_TRY(check_level(p, l));
-  if (!ms_out || reps < 1 || blocks < 1 || kind < 0 || kind > 17) return fail(MGCMT_ERR_INVALID, "bad arguments");
+  if (!ms_out || reps < 1 || blocks < 1 || kind < 0 || (kind > 17 && (kind < 20 || kind > 23))) return fail(MGCMT_ERR_INVALID, "bad arguments");
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
@@ -1312,7 +1312,8 @@ int mgcmt_bandwidth_probe(mgcmt_plan* p, int l, int kind, int blocks, int reps, 
   MG_HIP(hipEventCreate(&a));
   MG_HIP(hipEventCreate(&b));
   auto go = [&]() {
-    if (kind <= 2) launch_probe(S(stream), kind, n, p->kvec(l, MGCMT_SLOT_V).p, p->kvec(l, MGCMT_SLOT_F).p, p->kvec(l, MGCMT_SLOT_T).p, blocks);
+    if (kind >= 20) launch_probe_issue(S(stream), kind - 20, 20000, blocks, p->kvec(l, MGCMT_SLOT_T).p);  // 64 x 20000 instructions per wave
+    else if (kind <= 2) launch_probe(S(stream), kind, n, p->kvec(l, MGCMT_SLOT_V).p, p->kvec(l, MGCMT_SLOT_F).p, p->kvec(l, MGCMT_SLOT_T).p, blocks);
     else  // marching pattern: `blocks` = rows per chunk
       // (kind - 3) % 3: one read stream / two read streams / two reads + one write; (kind - 3) / 3: columns a wave
       // writes out of the 128 it reads: 128 (no overlap), 124 (unaligned), 112 (the fused kernels' geometry), 96
