@@ -11,7 +11,8 @@ per cycle x cycles / wall time of the whole cycles (all levels, transfers and th
 lower bound on the fine smoother's own rate, which `roofline` reports from HIP events around the fine-level passes
 alone.  The same line also carries the red-black pass (`roofline_rb`, north_star's target kernel), the
 reference-faithful cycle (V(4,4) below the top level, MGCMTSolver.py:320), the red-black cycle, the one-GPU time of
-the multi-GPU configuration (`strong_scaling_base`) and the CPU baselines.
+the multi-GPU configuration (`strong_scaling_base`), the cycle on the Mehrstellen operator, the reference's default
+lexicographic Gauss-Seidel cycle at 4096^2 (`cycle_gauss_seidel_lexicographic`) and the CPU baselines.
 
 N > 1: BASELINE.json configs[3] — 32768^2, V(2,2) red-black, row strips with RCCL halo exchange (strong scaling:
 the grid is fixed as N grows; multigridcmt_amd/dist_bench.py).
@@ -296,6 +297,29 @@ def main(argv=None):
             m9.close()
         except Exception as e:
             out["cycle_mehrstellen"] = {"value": None, "error": str(e)}
+    if not args.no_extras:
+        # the reference's DEFAULT smoother — lexicographic Gauss-Seidel (MGCMTSolver.py:210-227; `smoother=None` ->
+        # `self.gseidel`, :291) — at BASELINE config 2's grid: V(2,2), and V(2,2) on top / V(4,4) below (:320), as a
+        # pipeline of waves with the sweeps of a smoothing step chained in one launch, against the one-workgroup kernel
+        try:
+            gl = min(g, 4096)
+            lx = Plan(laplacian_operator(gl, "2d") * (-1.0 / np.pi ** 2), args.lowest, nvec=1, device=0)
+            lx.set_shifts([0.0])
+            lx.upload(0, _lib.SLOT_F, 0, np.random.RandomState(2).rand(gl * gl))
+            rec = {"workload": "2D Laplacian %d^2 fp64, lexicographic Gauss-Seidel (the reference's default smoother), 1xMI355X" % gl}
+            for name_, nuc in (("V22", 2), ("V22_top_V44_below", 4)):
+                lx.fill(0, _lib.SLOT_V, 0, 0.0)
+                t = time_cycles(lx, 5, 3, lambda: lx.vcycle(2, 2, _lib.GS_LEX, omega=1.0, k=1, nu_coarse=nuc))
+                rec[name_ + "_ms_per_step"] = t / 5 * 1e3
+            lx.set_option(_lib.OPT_LEX_WAVE, 0)
+            lx.fill(0, _lib.SLOT_V, 0, 0.0)
+            t = time_cycles(lx, 2, 1, lambda: lx.vcycle(2, 2, _lib.GS_LEX, omega=1.0, k=1, nu_coarse=2))
+            rec["V22_one_workgroup_ms_per_step"] = t / 2 * 1e3
+            rec["speedup_V22"] = rec["V22_one_workgroup_ms_per_step"] / rec["V22_ms_per_step"]
+            out["cycle_gauss_seidel_lexicographic"] = rec
+            lx.close()
+        except Exception as e:
+            out["cycle_gauss_seidel_lexicographic"] = {"value": None, "error": str(e)}
     if not args.no_extras and g == 16384:
         # BASELINE config 4's workload (32768^2, V(2,2) red-black) on this ONE GPU: the base of the strong-scaling
         # curve `bench.py --gpus N` continues.  Right-hand side: the 16384^2 random field interpolated on the device.

@@ -141,6 +141,7 @@ def test_bench_line_contract(capsys, monkeypatch):
     assert abs(out["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-12
     assert len(out["residual_reduction_per_cycle"]) == 10 and out["residual_reduction_per_cycle"][-1] < 1e-3
     assert out["cycle_mehrstellen"]["four_colour"]["ms_per_step"] > 0 and out["cycle_mehrstellen"]["wjacobi"]["value"] > 0
+    assert out["cycle_gauss_seidel_lexicographic"]["V22_ms_per_step"] > 0 and out["cycle_gauss_seidel_lexicographic"]["speedup_V22"] > 0
 
 
 def test_lexwave_isa_keeps_load_destinations_in_place():
