@@ -28,59 +28,68 @@ def compile_isa(out, source="kernels_lexwave.hip"):
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
+def audit_loop(loop):
+    dests = set()
+    seen = {}
+    for n, t in enumerate(loop):
+        # (hand-counted = inside an asm statement: the compiler's own loads can take the same scalar-base form)
+        m = re.search(r"global_load_dwordx2 v\[(\d+):(\d+)\], v\d+, s\[", t) if n and "#ASMSTART" in loop[n - 1] else None
+        if m:
+            dests.update({int(m.group(1)), int(m.group(2))})
+            seen[m.group(1)] = seen.get(m.group(1), 0) + 1
+    bad = []
+    # every slot has registers of its own: a destination that two loads of the loop share is a temporary the slot is
+    # copied out of afterwards — while the load is in flight
+    for reg, count in seen.items():
+        if count > 1:
+            bad.append("v[%s:..] is the destination of %d hand-counted loads" % (reg, count))
+    for t in loop:
+        m = re.match(r"v_mov_b32\S*\s+v(\d+), v(\d+)", t)
+        if m and int(m.group(2)) in dests and "dpp" not in t:
+            bad.append(t)
+        m = re.search(r"global_store_dwordx2 v\[(\d+):(\d+)\]", t)
+        if m and int(m.group(1)) in dests:
+            bad.append(t)
+        m = re.search(r"global_load_dwordx2 v\[\d+:\d+\], v\[(\d+):(\d+)\], off", t)
+        if m and int(m.group(1)) in dests:
+            bad.append(t)
+        m = re.search(r"global_load_dwordx2 v\[\d+:\d+\], v(\d+), s\[", t)
+        if m and int(m.group(1)) in dests:
+            bad.append(t)
+        m = re.search(r"scratch_store\S* .*?v\[?(\d+)", t)
+        if m and int(m.group(1)) in dests:
+            bad.append(t)
+    # the compiler's own waits inside the loop must be full drains of the slow path only: a partial one (vmcnt(N), N > 1)
+    # means it believes a load pending on a slot register and throttles the pipeline on the hardware's counter
+    for i, t in enumerate(loop):
+        m = re.search(r"s_waitcnt vmcnt\((\d+)\)", t)
+        if m and int(m.group(1)) > 1 and "#ASMSTART" not in loop[i - 1]:
+            bad.append("compiler-inserted " + t)
+    return dests, bad
+
+
 def audit(path, kernel="k_lex_wave"):
     lines = open(path).read().split("\n")
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN5mgcmt.*" + kernel + r".*:", l)]
     report = []
     for k, s in enumerate(starts):
         body = lines[s:(starts[k + 1] if k + 1 < len(starts) else len(lines))]
-        counted = [i for i, l in enumerate(body) if (m := re.search(r"s_waitcnt vmcnt\((\d+)\)", l)) and int(m.group(1)) >= 10
-                   and "#ASMSTART" in body[i - 1]]
-        if not counted:
-            report.append((k, 0, ["no hand-counted wait found"]))
+        # every top-level loop with hand-counted waits is audited by itself (kernels_lexpair.hip has one per wave role: the
+        # roles are different waves, the same register numbers in both mean nothing)
+        headers = [i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l) and "Loop Header: Depth=1" in l]
+        segments = []
+        for h, start in enumerate(headers):
+            seg = body[start:(headers[h + 1] if h + 1 < len(headers) else len(body))]
+            if any((m := re.search(r"s_waitcnt vmcnt\((\d+)\)", l)) and int(m.group(1)) >= 6 and n and "#ASMSTART" in seg[n - 1] for n, l in enumerate(seg)):
+                segments.append(seg)
+        if not segments:
+            report.append((k, 0, ["no loop with hand-counted waits found"]))
             continue
-        # the row loop: from its header (the last depth-1 loop header before the first hand-counted wait) to the end
-        headers = [i for i, l in enumerate(body[:counted[0]]) if re.match(r"^\.LBB\d+_\d+:", l) and "Loop Header: Depth=1" in l]
-        if not headers:
-            report.append((k, 0, ["no loop header before the first hand-counted wait"]))
-            continue
-        loop = [l.strip() for l in body[headers[-1]:]]
-        dests = set()
-        seen = {}
-        for n, t in enumerate(loop):
-            # (hand-counted = inside an asm statement: the compiler's own loads can take the same scalar-base form)
-            m = re.search(r"global_load_dwordx2 v\[(\d+):(\d+)\], v\d+, s\[", t) if n and "#ASMSTART" in loop[n - 1] else None
-            if m:
-                dests.update({int(m.group(1)), int(m.group(2))})
-                seen[m.group(1)] = seen.get(m.group(1), 0) + 1
-        bad = []
-        # every slot has registers of its own: a destination that two loads of the loop share is a temporary the slot is
-        # copied out of afterwards — while the load is in flight
-        for reg, count in seen.items():
-            if count > 1:
-                bad.append("v[%s:..] is the destination of %d hand-counted loads" % (reg, count))
-        for t in loop:
-            m = re.match(r"v_mov_b32\S*\s+v(\d+), v(\d+)", t)
-            if m and int(m.group(2)) in dests and "dpp" not in t:
-                bad.append(t)
-            m = re.search(r"global_store_dwordx2 v\[(\d+):(\d+)\]", t)
-            if m and int(m.group(1)) in dests:
-                bad.append(t)
-            m = re.search(r"global_load_dwordx2 v\[\d+:\d+\], v\[(\d+):(\d+)\], off", t)
-            if m and int(m.group(1)) in dests:
-                bad.append(t)
-            m = re.search(r"global_load_dwordx2 v\[\d+:\d+\], v(\d+), s\[", t)
-            if m and int(m.group(1)) in dests:
-                bad.append(t)
-            m = re.search(r"scratch_store\S* .*?v\[?(\d+)", t)
-            if m and int(m.group(1)) in dests:
-                bad.append(t)
-        # the compiler's own waits inside the loop must be full drains of the slow path only: a partial one (vmcnt(N), N > 1)
-        # means it believes a load pending on a slot register and throttles the pipeline on the hardware's counter
-        for i, t in enumerate(loop):
-            m = re.search(r"s_waitcnt vmcnt\((\d+)\)", t)
-            if m and int(m.group(1)) > 1 and "#ASMSTART" not in loop[i - 1]:
-                bad.append("compiler-inserted " + t)
+        dests, bad = set(), []
+        for seg in segments:
+            d, b = audit_loop([l.strip() for l in seg])
+            dests |= d
+            bad += b
         report.append((k, len(dests), bad))
     return report
 
