@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MGCMT_ABI_VERSION 3
+#define MGCMT_ABI_VERSION 4
 #define MGCMT_MAX_TERMS 4
 #define MGCMT_HALO_ROWS 8 /* rows of halo kept above and below every level's vectors */
 
@@ -125,10 +125,15 @@ int mgcmt_prolong_correct(mgcmt_plan* plan, int level, int k, void* stream);
 /* V[last] <- (A_last - mu I)^-1 F[last]                  (spsolve, MGCMTSolver.py:305-308) */
 int mgcmt_coarse_solve(mgcmt_plan* plan, int level, int k, void* stream);
 /* one V-cycle from `level` down: vcycle (:281-329) for k == 1, vcycle_matrix (:375-436, incl. the
- * Gram-Schmidt at every non-coarsest level, :434) when gram_schmidt != 0.  nu_coarse is the sweep
- * count on the levels below `level` (the reference does not forward nu1/nu2, so 4: :320,:426). */
+ * Gram-Schmidt at every non-coarsest level, :434) with MGCMT_CYCLE_GRAM_SCHMIDT in cycle_flags.  nu_coarse is the
+ * sweep count on the levels below `level` (the reference does not forward nu1/nu2, so 4: :320,:426).
+ * MGCMT_CYCLE_ZERO_START: the caller vouches that V[level] is zero, the way the reference's eigen-drivers start every
+ * cycle (1DPotMatrixVcycle.py:70, v0 = zeros): the first pass then neither reads nor needs V cleared (ABI 4; the
+ * argument was the 0 / 1 Gram-Schmidt switch before, which keeps its meaning). */
+#define MGCMT_CYCLE_GRAM_SCHMIDT 1
+#define MGCMT_CYCLE_ZERO_START 2
 int mgcmt_vcycle(mgcmt_plan* plan, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k,
-                 int gram_schmidt, void* stream);
+                 int cycle_flags, void* stream);
 /* twogrid (:331-371): exact solve of (R A P - mu I) on level+1 */
 int mgcmt_twogrid(mgcmt_plan* plan, int level, int nu1, int nu2, int kind, double omega, int k, void* stream);
 
@@ -185,6 +190,17 @@ int mgcmt_fused_pass(mgcmt_plan* plan, int level, int kind, int nsweep, double o
 int mgcmt_fused_max_sweeps(const mgcmt_plan* plan, int level, int kind, int* max_sweeps);
 /* how many pre-smoothing sweeps a mode-1 pass with `nsweep` post-smoothing sweeps can recompute on that level */
 int mgcmt_fused_max_recompute(const mgcmt_plan* plan, int level, int kind, int nsweep, int* max_recompute);
+/* How the library recognised the operator of `level` (which decides the kernels the level runs on): MGCMT_OPK_GENERAL
+ * (Kronecker terms with variable factors), MGCMT_OPK_FIVE_POINT (constant 5-point / 3-point: the scaled, shifted
+ * Laplacian of MGCMTStencilMaker.py:15-25), MGCMT_OPK_FIVE_DIAG (the same plus a product potential on the diagonal),
+ * MGCMT_OPK_NINE_CONST (Galerkin coarsenings R*A*P, MGCMTSolver.py:318, of a constant operator), MGCMT_OPK_NINE_VAR
+ * (the same plus one term with variable factors: the coarsened product potential). */
+#define MGCMT_OPK_GENERAL 0
+#define MGCMT_OPK_FIVE_POINT 1
+#define MGCMT_OPK_FIVE_DIAG 2
+#define MGCMT_OPK_NINE_CONST 3
+#define MGCMT_OPK_NINE_VAR 4
+int mgcmt_level_operator_kind(const mgcmt_plan* plan, int level, int* kind);
 
 /* ---- multi-GPU: row strips with neighbour halo exchange --------------------------------------------
  * A strip plan (mgcmt_plan_desc.row_begin/row_end/strip_levels) gets a communicator; every exchange below is then

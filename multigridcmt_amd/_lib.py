@@ -18,7 +18,7 @@ OP_A, OP_M = 0, 1
 HALO_ROWS = 8
 MAX_TERMS = 4
 MAX_VEC = 32
-ABI_VERSION = 3
+ABI_VERSION = 4
 OPT_FUSED = 0
 OPT_FUSED_ROWS = 1
 OPT_TAIL = 4
@@ -55,6 +55,8 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, _dp, c_int)
 UNIQUE_ID_BYTES = 128
 COMM_OPT_OVERLAP, COMM_OPT_SPLIT, COMM_OPT_SELF_RING = 0, 1, 2
 SHARDED_V_HALO_VALID, SHARDED_F_HALO_VALID = 1, 2
+CYCLE_GRAM_SCHMIDT, CYCLE_ZERO_START = 1, 2    # cycle_flags of mgcmt_vcycle
+OPK_GENERAL, OPK_FIVE_POINT, OPK_FIVE_DIAG, OPK_NINE_CONST, OPK_NINE_VAR = 0, 1, 2, 3, 4    # mgcmt_level_operator_kind
 HALO_RING = 0x100
 
 _SIGNATURES = {
@@ -98,6 +100,7 @@ _SIGNATURES = {
                                     POINTER(c_double), c_void_p]),
     "mgcmt_gramschmidt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mgcmt_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mgcmt_level_operator_kind": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int)]),
     "mgcmt_fused_pass": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p]),
     "mgcmt_fused_max_sweeps": (c_int, [c_void_p, c_int, c_int, POINTER(c_int)]),
     "mgcmt_fused_max_recompute": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int)]),

@@ -40,6 +40,20 @@ constexpr int kWavesPerBlock = MGCMT_FUSED_WAVES;
 #define MGCMT_FUSED_DEPTH9 1
 #endif
 constexpr int kDepth9 = MGCMT_FUSED_DEPTH9;  // 9-point policies carry wider windows: shallower batches keep two or three waves per SIMD
+// Register sets of prefetched rows in rotation: one is consumed while the other NS - 1 are in flight.  The 9-point
+// passes have single-row batches, and with two sets a wave has ONE row of loads outstanding while it works — on the
+// Galerkin levels that is a memory-latency bound (waves waiting 50-60 % of their cycles); more sets of one row cost
+// 6 registers each (a right-hand-side pair and a correction value) instead of the 3 x 12 of a deeper batch.
+#ifndef MGCMT_FUSED_SETS9
+#define MGCMT_FUSED_SETS9 2
+#endif
+constexpr int kSets9 = MGCMT_FUSED_SETS9;
+// the largest number of sets <= want that divides the batches of a loop body (the rotation must close at the latch)
+constexpr int sets_for(int batches, int want) {
+  int n = want < 2 ? 2 : want;
+  while (batches % n != 0) --n;
+  return n;
+}
 
 struct FusedArgs {
   const double* vin;
@@ -296,6 +310,62 @@ struct Op9 {
   }
 };
 
+// A constant part as in Op9c (Toeplitz-but-last terms: the Galerkin coarsenings of the scaled Laplacian) plus ONE term
+// X (x) Y with arbitrary tridiagonal factors (the coarsened product potential of a square well): the eight constant
+// off-diagonal coefficients stay scalars, the variable term costs 11 multiply-adds and the diagonal one more — 29
+// against the 39 + 3 of treating all three terms as variable (Op9<3>), which is what the Galerkin levels of BASELINE
+// config 5 ran on (vector-ALU bound: 0.93 of the 1.46 ms of an 8192^2 cycle).  Column factors of the lane's two
+// columns in registers, the row's three factors through the LDS ring like Op9's.
+struct Op9cv {
+  static constexpr bool kNine = true;
+  static constexpr bool kBigBody = false;
+  static constexpr bool kSpecialRow = true;
+  static constexpr int kRowValues = 3;
+  Op9c base;
+  double ya[3], yb[3];  // lower, diag, upper of Y at columns ja, ja+1
+  double x[3];          // lower, diag, upper of X at the row being updated
+  __device__ __forceinline__ void init(const FusedArgs& a, int q, long ja, long nc) {
+    base.init(a, q, ja, nc);
+    const long j = ja < 0 ? 0 : (ja > nc - 2 ? nc - 2 : ja);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      ya[p] = a.Y[0][p * a.ldy + j];
+      yb[p] = a.Y[0][p * a.ldy + j + 1];
+      x[p] = 0.0;
+    }
+  }
+  __device__ __forceinline__ double fetch_row(const FusedArgs& a, long rl, int lane) const {
+    const int k = lane < 3 ? lane : 2;
+    return a.X[0][k * a.ldx + rl];
+  }
+  __device__ __forceinline__ void set_row(const FusedArgs&, int, const double* ring_row) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) x[p] = ring_row[p];
+  }
+  __device__ __forceinline__ bool special_row(int row) const { return base.special_row(row); }
+  template <int COL>
+  __device__ __forceinline__ void eval(const double* n, const double* c, const double* s, double& off, double& dg, double& inv) const {
+    double o, dd, unused;
+    base.template eval<COL>(n, c, s, o, dd, unused);
+    const double* y = COL == 0 ? ya : yb;
+    const double rn = fma(y[2], n[2], fma(y[1], n[1], y[0] * n[0]));
+    const double rc = fma(y[2], c[2], y[0] * c[0]);
+    const double rs = fma(y[2], s[2], fma(y[1], s[1], y[0] * s[0]));
+    off = fma(x[2], rs, fma(x[1], rc, fma(x[0], rn, o)));
+    dg = fma(x[1], y[1], dd);
+    inv = fast_reciprocal(dg);
+  }
+  // the last row of the constant part (its X factors' last diagonal entry differs); the variable term's row factors
+  // come from the arrays and need no patch
+  template <int COL>
+  __device__ __forceinline__ void fix_special(const double* c, double& off, double& dg, double& inv) const {
+    double unused;
+    base.template fix_special<COL>(c, off, dg, unused);
+    dg = fma(x[1], COL == 0 ? ya[1] : yb[1], dg);
+    inv = fast_reciprocal(dg);
+  }
+};
+
 // constant 5-point operator plus MD product potentials p_m(i) q_m(j) on the diagonal (a square well on a scaled
 // Laplacian, PotWellSolver.py:150-153 carried to 2-D): the off-diagonal part is Op5's three scalars, the lane keeps
 // q_m of its two columns, p_m of a row travels through the LDS ring like Op9's row factors.
@@ -430,7 +500,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   constexpr bool INPLACE = Shape::inplace;
   constexpr int XL = Shape::XL;
   constexpr int B = Shape::body;              // marching steps per loop iteration
-  static_assert(B % D == 0 && (B / D) % 2 == 0, "the loop body must hold an even number of prefetch batches");
+  constexpr int NS = NINE ? sets_for(B / D, kSets9) : 2;  // register sets of D prefetched rows each
+  static_assert(B % D == 0 && NS >= 2 && (B / D) % NS == 0, "the loop body must hold a whole number of rotations of the prefetch sets");
   constexpr int FL = S + E + 1 + XL;          // delay of the right-hand side between its load and its last use
   constexpr bool FRING = FL <= B;             // short enough for a rotating file of B; otherwise a shifting one
   constexpr int FN = FRING ? B : FL;
@@ -493,8 +564,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   OP op;
   op.init(a, q, ja, nc);
 
-  // Two register sets A/B of D rows each, used alternately: one is refilled while the other is
-  // consumed, so every load has D rows of work between its issue and its use.
+  // NS register sets of D rows each, used in rotation: one is consumed while the others are in flight (refilled
+  // in order), so every load has (NS - 1) * D rows of work between its issue and its use.
   struct Row {
     double2 v, f;
     double e;
@@ -504,7 +575,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   constexpr int kRing = 16;  // rows of operator values kept in LDS; a stage lags at most S + E + 1 <= 10 rows
   __shared__ double s_ring[kWavesPerBlock][RV > 0 ? kRing * RV : 1];
   double* ring = s_ring[wave];
-  Row setA[D], setB[D];
+  Row sets[NS][D];
   // rows are fetched in order; the row is clamped into the allocation with min/max (no control flow near a load)
   int frow = rstart;
   auto fetch = [&](Row& r) __attribute__((always_inline)) {
@@ -526,7 +597,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
     ++frow;
   };
 #pragma unroll
-  for (int u = 0; u < D; ++u) fetch(setA[u]);
+  for (int n = 0; n + 1 < NS; ++n)
+#pragma unroll
+    for (int u = 0; u < D; ++u) fetch(sets[n][u]);
 
   // stage windows: w[s] is the input of stage s+1; w[S] (RESTRICT) the input of the residual stage.  Three rows
   // each, rotating: at loop position T stage s finds the row above / the row it updates / the row below (just
@@ -839,12 +912,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
     }
   };
 
-  // B steps per iteration in B/D batches: fetch a whole set, then process the other one.
+  // B steps per iteration in B/D batches: refill the set consumed last, then process the oldest one.
   auto body = [&](auto chk, const int base) __attribute__((always_inline)) {
     static_for<0, B / D>([&](auto g) __attribute__((always_inline)) {
       constexpr int G = decltype(g)::value;
-      Row* cur = (G % 2 == 0) ? setA : setB;
-      Row* nxt = (G % 2 == 0) ? setB : setA;
+      Row* cur = sets[G % NS];
+      Row* nxt = sets[(G + NS - 1) % NS];
 #pragma unroll
       for (int u = 0; u < D; ++u) fetch(nxt[u]);
       static_for<0, D>([&](auto u) __attribute__((always_inline)) {
@@ -974,5 +1047,6 @@ void launch_fused_op9c(hipStream_t s, const fused::FusedArgs& a, int multicolour
 void launch_fused_op9(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);    // two terms
 void launch_fused_op9m3(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);  // three terms
 void launch_fused_op5v(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);   // 5-point + product potential
+void launch_fused_op9cv(hipStream_t s, const fused::FusedArgs& a, int multicolour, int nsweep, int flags, int k);  // constant 9-point + one variable term
 
 }  // namespace mgcmt

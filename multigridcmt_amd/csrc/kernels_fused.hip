@@ -13,7 +13,7 @@ constexpr long kFusedMinCols = MGCMT_FUSED_MIN_COLS;
 // separable operators of two or three Kronecker terms (Laplacian plus potential).  Narrow levels run too (one partly filled wave per
 // chunk): a fused pass there replaces four to nine tiny launches, which is what small levels cost.
 bool fused_supported(const KGrid& g, const KOp& op) {
-  return g.coarsen_rows && g.nr >= 4 && g.nc >= kFusedMinCols && (g.nc & 1) == 0 && (g.nr & 1) == 0 && (op.five_point || op.five_diag || op.nine_const || op.nterms == 2 || op.nterms == 3);
+  return g.coarsen_rows && g.nr >= 4 && g.nc >= kFusedMinCols && (g.nc & 1) == 0 && (g.nr & 1) == 0 && (op.five_point || op.five_diag || op.nine_const || op.nine_var || op.nterms == 2 || op.nterms == 3);
 }
 
 // sweeps one pass can fuse.  A 9-point four-colour sweep is four stages: two of them plus the restriction read nine
@@ -81,6 +81,17 @@ void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, K
     a.c9corner = op.c9corner;
     a.last_row = last_row;
     launch_fused_op9c(s, a, multicolour, nsweep, flags, k);
+  } else if (op.nine_var) {
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) a.c9[i][j] = op.c9[i][j];
+      a.c9row[i] = op.c9row[i];
+      a.c9col[i] = op.c9col[i];
+    }
+    a.c9corner = op.c9corner;
+    a.last_row = last_row;
+    a.X[0] = op.vX;
+    a.Y[0] = op.vY;
+    launch_fused_op9cv(s, a, multicolour, nsweep, flags, k);
   } else if (op.nterms == 3) {
     launch_fused_op9m3(s, a, multicolour, nsweep, flags, k);
   } else {

@@ -29,6 +29,12 @@ struct KOp {
   // coefficients on the last column, and the corner's diagonal
   int nine_const;
   double c9[3][3], c9row[3], c9col[3], c9corner;
+  // nine_var: some terms are Toeplitz-but-last (their sum is c9 / c9row / c9col / c9corner as above), ONE term has
+  // arbitrary tridiagonal factors vX, vY ([lower | diag | upper], leading dimensions ldx / ldy) — the Galerkin levels of
+  // a constant operator plus a product potential (square well, PotWellSolver.py:150-153 carried to 2-D)
+  int nine_var;
+  const double* vX;
+  const double* vY;
   // five_diag: a constant 5-point part (c0/cn/cw) plus ndiag (1 or 2) terms whose factors are both diagonal — a
   // product potential p(i) q(j) on top of a scaled Laplacian (square well): dX[m][row], dY[m][col] are the diagonals
   int five_diag, ndiag;

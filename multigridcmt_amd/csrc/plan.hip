@@ -169,10 +169,17 @@ int upload_op(const HostOp& h, const Level& L, int dim, DevOp* d) {
     };
     bool ok = true;
     double c9[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, crow[3] = {0, 0, 0}, ccol[3] = {0, 0, 0}, corner = 0;
+    int nconst = 0, nvar = 0, var_term = -1;
     for (int m = 0; m < h.nterms && ok; ++m) {
       double x[3], y[3], xl, yl;
-      ok = toeplitz_but_last(h.X[m], &x[0], &x[1], &x[2], &xl) && toeplitz_but_last(h.Y[m], &y[0], &y[1], &y[2], &yl);
-      if (!ok) break;
+      if (!(toeplitz_but_last(h.X[m], &x[0], &x[1], &x[2], &xl) && toeplitz_but_last(h.Y[m], &y[0], &y[1], &y[2], &yl))) {
+        // a term with variable factors: one of them may ride on top of the constant part (nine_var)
+        ++nvar;
+        var_term = m;
+        ok = nvar <= 1;
+        continue;
+      }
+      ++nconst;
       for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) c9[a][b] += x[a] * y[b];
       for (int b = 0; b < 3; ++b) crow[b] += xl * y[b];   // last row: X's diagonal entry is the modified one
@@ -180,9 +187,15 @@ int upload_op(const HostOp& h, const Level& L, int dim, DevOp* d) {
       corner += xl * yl;
       crow[1] += 0.0;
     }
-    if (ok) {
+    if (ok && nconst >= 1) {
       // on the last row the centre coefficient of the last column is the corner; crow[1] is the centre elsewhere
-      k.nine_const = 1;
+      if (nvar == 0) {
+        k.nine_const = 1;
+      } else {
+        k.nine_var = 1;
+        k.vX = k.X[var_term];
+        k.vY = k.Y[var_term];
+      }
       for (int a = 0; a < 3; ++a) {
         for (int b = 0; b < 3; ++b) k.c9[a][b] = c9[a][b];
         k.c9row[a] = crow[a];
@@ -292,8 +305,7 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
     const size_t need_carry = band ? need_band : need_scan, need_sync = 2 + 4 * (size_t)p->nvec * blocks;  // (2 words used; the rest is the diagnostic build's per-block record)
     if (need_carry > p->lex_carry_doubles || need_sync > p->lex_sync_words) {
       MG_HIP(hipStreamSynchronize(s));
-      if (p->d_rq) (void)hipFree(p->d_rq);
-  if (p->lex_carry) (void)hipFree(p->lex_carry);
+      if (p->lex_carry) (void)hipFree(p->lex_carry);
       if (p->lex_sync) (void)hipFree(p->lex_sync);
       p->lex_carry = nullptr;
       p->lex_sync = nullptr;
@@ -345,6 +357,7 @@ int smooth_impl(mgcmt_plan* p, int l, int kind, int nu, double omega, int k, hip
   MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));
   const KGrid g = p->kgrid(l);
   const KOp& op = L.dA.k;
+  if (nu <= 0) return MGCMT_OK;  // (a V(0,nu2) cycle: nothing to launch — the chained lexicographic sweeps size their scratch by nu)
   if (fused_level(p, l, kind)) {
     MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
     for (int left = nu; left > 0;) {
@@ -638,8 +651,12 @@ int run_tail(mgcmt_plan* p, int lt, int kind, int nu, double omega, int k, hipSt
   return post_launch();
 }
 
-int vcycle_body(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k, int gram_schmidt,
+int vcycle_body(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k, int cycle_flags,
                 hipStream_t s) {
+  const int gram_schmidt = cycle_flags & MGCMT_CYCLE_GRAM_SCHMIDT;
+  // MGCMT_CYCLE_ZERO_START: the caller vouches that the iterate on `level` is zero — the first pass takes that as a
+  // flag (V is neither cleared nor read; where no fused pass runs, down_leg clears it)
+  const bool zero_start = (cycle_flags & MGCMT_CYCLE_ZERO_START) != 0;
   const int last = (int)p->levels.size() - 1;
   const int lt = tail_level(p, level, kind, nu_coarse, gram_schmidt);
   const int bottom = lt > 0 ? lt : last;  // the levels level .. bottom-1 run as fused passes / single launches
@@ -649,7 +666,7 @@ int vcycle_body(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int k
     const int nu_up = l == level ? nu2 : nu_coarse;
     bool sz = false;
     // the up-leg can only recompute the unstored sweeps if it runs a fused pass itself (>= 1 post-smoothing sweep)
-    MG_TRY(down_leg(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, l > level, s, nu_up >= 1 ? &recompute[l] : nullptr, &sz, nu_up));
+    MG_TRY(down_leg(p, l, kind, l == level ? nu1 : nu_coarse, omega, k, l > level || zero_start, s, nu_up >= 1 ? &recompute[l] : nullptr, &sz, nu_up));
     still_zero[l] = sz;
   }
   if (lt > 0) MG_TRY(run_tail(p, lt, kind, nu_coarse, omega, k, s));
@@ -927,16 +944,17 @@ int mgcmt_coarse_solve(mgcmt_plan* p, int l, int k, void* stream) {
   return coarse_solve_impl(p, l, k, S(stream));
 }
 
-int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k, int gram_schmidt,
+int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k, int cycle_flags,
                  void* stream) {
   MG_TRY(check_level(p, level));
   MG_TRY(check_k(p, k));
   if (nu1 < 0 || nu2 < 0 || nu_coarse < 0) return fail(MGCMT_ERR_INVALID, "sweep counts must be >= 0");
+  if (cycle_flags & ~(MGCMT_CYCLE_GRAM_SCHMIDT | MGCMT_CYCLE_ZERO_START)) return fail(MGCMT_ERR_INVALID, "unknown cycle flag");
   hipStream_t s = S(stream);
-  if (!p->use_graph) return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt, s);
+  if (!p->use_graph) return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, cycle_flags, s);
 
   char buf[160];
-  snprintf(buf, sizeof(buf), "%d/%d/%d/%d/%d/%.17g/%d/%d", level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt);
+  snprintf(buf, sizeof(buf), "%d/%d/%d/%d/%d/%.17g/%d/%d", level, nu1, nu2, nu_coarse, kind, omega, k, cycle_flags);
   const std::string params(buf);
   std::string key = params;
   for (const Level& L : p->levels) {
@@ -956,19 +974,19 @@ int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int 
     return MGCMT_OK;
   }
   // the first cycle with these parameters runs eagerly: it allocates, factors and queries occupancies
-  if (p->cycle_seen[params]++ == 0) return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt, s);
+  if (p->cycle_seen[params]++ == 0) return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, cycle_flags, s);
   MG_TRY(ensure_coarse_factor(p, (int)p->levels.size() - 1, k, s));
   if (!p->capture_stream && hipStreamCreate(&p->capture_stream) != hipSuccess) {
     p->use_graph = false;
     (void)hipGetLastError();
-    return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt, s);
+    return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, cycle_flags, s);
   }
   if (hipStreamBeginCapture(p->capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     p->use_graph = false;
     (void)hipGetLastError();
-    return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt, s);
+    return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, cycle_flags, s);
   }
-  const int rc = vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, gram_schmidt, p->capture_stream);
+  const int rc = vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, cycle_flags, p->capture_stream);
   hipGraph_t graph = nullptr;
   const hipError_t end = hipStreamEndCapture(p->capture_stream, &graph);
   if (rc != MGCMT_OK || end != hipSuccess || !graph) {
@@ -1231,6 +1249,14 @@ int mgcmt_fused_max_recompute(const mgcmt_plan* p, int l, int kind, int nsweep, 
   MG_TRY(check_level(p, l));
   if (!max_recompute) return fail(MGCMT_ERR_INVALID, "null output");
   *max_recompute = fused_level(p, l, kind) ? fused_max_recompute(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0, nsweep) : 0;
+  return MGCMT_OK;
+}
+
+int mgcmt_level_operator_kind(const mgcmt_plan* p, int l, int* kind) {
+  MG_TRY(check_level(p, l));
+  if (!kind) return fail(MGCMT_ERR_INVALID, "null output");
+  const KOp& k = p->levels[l].dA.k;
+  *kind = k.five_point ? MGCMT_OPK_FIVE_POINT : k.five_diag ? MGCMT_OPK_FIVE_DIAG : k.nine_const ? MGCMT_OPK_NINE_CONST : k.nine_var ? MGCMT_OPK_NINE_VAR : MGCMT_OPK_GENERAL;
   return MGCMT_OK;
 }
 

@@ -472,8 +472,7 @@ int mgcmt_sharded_vcycle(mgcmt_plan* p, mgcmt_plan* coarse, int nu1, int nu2, in
   // the coarse problem: all-gather, the same sub-cycle on every rank, own rows of the correction with halo rows
   MG_TRY(mgcmt_gather_coarse(p, ls, MGCMT_SLOT_F, coarse, MGCMT_SLOT_F, stream));
   MG_TRY(ensure_slot(coarse, 0, MGCMT_SLOT_V));
-  launch_fill(s, coarse->kvec(0, MGCMT_SLOT_V).p, coarse->interior(0), 0.0);
-  MG_TRY(mgcmt_vcycle(coarse, 0, nu_coarse, nu_coarse, nu_coarse, kind, omega, 1, 0, stream));
+  MG_TRY(mgcmt_vcycle(coarse, 0, nu_coarse, nu_coarse, nu_coarse, kind, omega, 1, MGCMT_CYCLE_ZERO_START, stream));
   {
     const Level& L = p->levels[ls];
     const long total = L.gr;

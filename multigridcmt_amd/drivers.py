@@ -214,8 +214,9 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
                      cycle of H (from a zero start) to the eigen-residual r = H x - rho x and minimises the Rayleigh
                      quotient over span{x, w} — the 2x2 problem of rqmin (MGCMTSolver.py:44-50) with the
                      preconditioned residual as the search direction.  All vector work stays in HBM: per iteration
-                     three fused linear combinations, one operator application and ONE Gram-matrix pass whose ten
-                     numbers are all the host sees.
+                     one V-cycle from a zero start (a flag: V is neither cleared nor read), one operator application (a
+                     row march at streaming speed), ONE Gram-matrix pass whose ten numbers are all the host sees, and
+                     ONE combination pass that writes the new x, H x and the next residual.
     Returns (rho, x); ``history`` (a list) receives rho after every cycle, ``stats`` (a dict) the seconds spent in
     the iteration loop alone (start vector generation and the host transfers excluded)."""
     from . import _lib
@@ -248,9 +249,9 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
     rho = plan.dot(0, X, AX)
     import time
     loop_start = time.perf_counter()
-    for _ in range(cycles):
-        plan.lincomb(0, [(1.0, AX), (-rho, X)], (F, 0))                               # r = H x - rho x
-        plan.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu, zero_start=True)        # w = B r
+    plan.lincomb(0, [(1.0, AX), (-rho, X)], (F, 0))                                   # r = H x - rho x
+    for it in range(cycles):
+        plan.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu, zero_start=True)        # w = B r  (V is not read: a flag)
         plan.apply(0, PW, AW)
         G = plan.gram(0, [X, PW, AX, AW])                                             # one pass, one host round trip
         xx, xw, ww = G[0, 0], G[0, 1], G[1, 1]
@@ -259,9 +260,15 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
         a, b = evecs[:, 0]
         nrm = np.sqrt(a * a * xx + 2 * a * b * xw + b * b * ww)                       # |a x + b w|
         a, b = a / nrm, b / nrm
-        plan.lincomb(0, [(a, X), (b, PW)], X)
-        plan.lincomb(0, [(a, AX), (b, AW)], AX)
         rho = float(evals[0])                                                         # = <x, H x> of the new x
+        # x <- a x + b w, H x <- a H x + b H w and the next residual H x - rho x in ONE pass over the four vectors
+        # (every input read once; the last iteration needs no residual)
+        last = it + 1 == cycles
+        coeffs = [[a, 0.0, -rho * a], [b, 0.0, -rho * b], [0.0, a, a], [0.0, b, b]]
+        if last:
+            plan.block_combine(0, [X, PW, AX, AW], [X, AX], [row[:2] for row in coeffs])
+        else:
+            plan.block_combine(0, [X, PW, AX, AW], [X, AX, (F, 0)], coeffs)
         if history is not None:
             history.append(rho)
     if stats is not None:

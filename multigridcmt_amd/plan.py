@@ -132,13 +132,11 @@ class Plan:
         check(_lib.lib().mgcmt_coarse_solve(self._h, level, k, stream))
 
     def vcycle(self, nu1, nu2, kind, omega=1.0, k=1, nu_coarse=4, gram_schmidt=False, level=0, stream=None, zero_start=False):
-        """zero_start: the iterate on `level` is to be taken as zero (it is cleared first; the sharded driver's
-        root sub-cycle starts this way)."""
-        if zero_start:
-            for q in range(k):
-                self.fill(level, SLOT_V, q, 0.0, stream)
-        check(_lib.lib().mgcmt_vcycle(self._h, level, nu1, nu2, nu_coarse, kind, c_double(omega), k,
-                                      1 if gram_schmidt else 0, stream))
+        """zero_start: the iterate on `level` is to be taken as zero, whatever V holds (the reference's eigen-drivers
+        start every cycle this way, 1DPotMatrixVcycle.py:70).  The library's first pass then neither reads V nor
+        needs it cleared (MGCMT_CYCLE_ZERO_START)."""
+        flags = (_lib.CYCLE_GRAM_SCHMIDT if gram_schmidt else 0) | (_lib.CYCLE_ZERO_START if zero_start else 0)
+        check(_lib.lib().mgcmt_vcycle(self._h, level, nu1, nu2, nu_coarse, kind, c_double(omega), k, flags, stream))
 
     def twogrid(self, nu1, nu2, kind, omega=1.0, k=1, level=0, stream=None):
         check(_lib.lib().mgcmt_twogrid(self._h, level, nu1, nu2, kind, c_double(omega), k, stream))
@@ -218,6 +216,12 @@ class Plan:
     def fused_max_sweeps(self, level, kind):
         n = c_int(0)
         check(_lib.lib().mgcmt_fused_max_sweeps(self._h, level, kind, ctypes.byref(n)))
+        return n.value
+
+    def operator_kind(self, level):
+        """One of _lib.OPK_*: how the library recognised the operator of `level` (decides the kernels it runs on)."""
+        n = ctypes.c_int(0)
+        check(_lib.lib().mgcmt_level_operator_kind(self._h, level, ctypes.byref(n)))
         return n.value
 
     def fused_max_recompute(self, level, kind, nsweep):

@@ -267,12 +267,17 @@ class MGCMTSolver:
             return self._vcycle_general(v0, f, A, kind, omega, int(nu1), int(nu2), int(nu_coarse), shift, int(lowest_level))
         plan = get_plan(op, int(lowest_level), nvec=1)
         plan.set_shifts([float(shift)])
-        plan.upload(0, SLOT_V, 0, np.asarray(v0, dtype=np.float64).reshape(-1))
+        v0 = np.asarray(v0, dtype=np.float64).reshape(-1)
+        zero_start = not v0.any()                 # a zero start vector (the reference's drivers) is a flag, not a transfer
+        if not zero_start:
+            plan.upload(0, SLOT_V, 0, v0)
+        elif kind is None:
+            plan.zero(0, SLOT_V, 0)
         plan.upload(0, SLOT_F, 0, np.asarray(f, dtype=np.float64).reshape(-1))
         if kind is None:
             self._cycle_with_host_smoother(plan, omega, int(nu1), int(nu2), int(nu_coarse), 1, [float(shift)], False)
         else:
-            plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=1, nu_coarse=int(nu_coarse))
+            plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=1, nu_coarse=int(nu_coarse), zero_start=zero_start)
         v = plan.download(0, SLOT_V, 0)
         if g == lowest_level:
             return v.reshape(n, 1)
@@ -361,15 +366,16 @@ class MGCMTSolver:
         plan.set_shifts(shifts)
         zero_start = not v0_matrix.any()          # the reference's callers pass zeros (1DPotMatrixVcycle.py:70): nothing to upload
         for i in range(k):
-            if zero_start:
-                plan.zero(0, SLOT_V, i)
-            else:
+            if not zero_start:
                 plan.upload(0, SLOT_V, i, v0_matrix[:, i])
             plan.upload(0, SLOT_F, i, f_matrix[:, i])
         if kind is None:
+            if zero_start:
+                for i in range(k):
+                    plan.zero(0, SLOT_V, i)
             self._cycle_with_host_smoother(plan, omega, int(nu1), int(nu2), int(nu_coarse), k, shifts, True)
         else:
-            plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=k, nu_coarse=int(nu_coarse), gram_schmidt=True)
+            plan.vcycle(int(nu1), int(nu2), kind, omega=omega, k=k, nu_coarse=int(nu_coarse), gram_schmidt=True, zero_start=zero_start)
         # columns are downloaded as contiguous rows of a (k, n) array; the (n, k) result is its transpose (a
         # column-major array: the same values and indexing as the reference's, without k strided scatters on the host)
         rows = np.empty((k, n))

@@ -156,6 +156,70 @@ def test_fused_general_separable_operator(backend, kind, omega):
 
 
 @pytest.mark.parametrize("kind,omega", [(_lib.WJACOBI, 2. / 3.), (_lib.GS_MC, 1.0)])
+@pytest.mark.parametrize("variable_laplacian", [False, True])
+def test_fused_constant_part_plus_product_term(backend, kind, omega, variable_laplacian):
+    """Scaled Laplacian plus a product potential p(i) q(j) (random, different in the two directions, non-zero on the last
+    row and column).  variable_laplacian = False: the Laplacian terms coarsen to Toeplitz-but-last factors and the
+    potential to ONE variable term — the Galerkin levels run the constant-part-plus-variable-term policy (Op9cv; the
+    square well of BASELINE config 5 is this case).  True: the Laplacian terms carry potentials a(x), b(y) of their own,
+    all three terms are variable — the general three-term policy (Op9<3>).  Fused against one-launch-per-operation
+    kernels (smoothing passes on level 1, whole cycles with several chunk lengths, the restricted residual) and
+    against the sparse oracle on the assembled matrix."""
+    from multigridcmt_amd.operators import StructuredOperator, tri_identity, tri_laplacian
+    from oracle.sparse_ref import RefSolver, RefStencilMaker
+    g = 128
+    rng = np.random.RandomState(23)
+    Lx, Ly = tri_laplacian(g) * SCALE, tri_laplacian(g) * SCALE
+    if variable_laplacian:
+        Lx[1] += 3.0 * rng.rand(g)
+        Ly[1] += 3.0 * rng.rand(g)
+    dp, dq = np.zeros((3, g)), np.zeros((3, g))
+    dp[1], dq[1] = 1.0 + 4.0 * rng.rand(g), 0.5 + 6.0 * rng.rand(g)
+    op = StructuredOperator("2d", g, [(tri_identity(g), Ly), (Lx, tri_identity(g)), (dp, dq)])
+    v0, f = rng.rand(g * g), rng.rand(g * g)
+    v1, f1 = rng.rand(g * g // 4), rng.rand(g * g // 4)
+    p = Plan(op, 8, nvec=1)
+    kinds = [p.operator_kind(l) for l in range(3)]
+    p.close()
+    assert kinds == ([_lib.OPK_GENERAL] * 3 if variable_laplacian else [_lib.OPK_FIVE_DIAG, _lib.OPK_NINE_VAR, _lib.OPK_NINE_VAR])
+    outs = []
+    for fused, rows in ((1, 0), (1, 6), (1, 22), (0, 0)):
+        p = Plan(op, 8, nvec=1)
+        p.set_option(_lib.OPT_FUSED, fused)
+        p.set_option(_lib.OPT_FUSED_ROWS, rows)
+        p.set_shifts([0.45])
+        res = []
+        for nu in (1, 2, 3):
+            p.upload(1, _lib.SLOT_V, 0, v1)
+            p.upload(1, _lib.SLOT_F, 0, f1)
+            p.smooth(1, kind, nu, omega)
+            res.append(p.download(1, _lib.SLOT_V, 0))
+        for nuc in (2, 1):
+            p.upload(0, _lib.SLOT_V, 0, v0)
+            p.upload(0, _lib.SLOT_F, 0, f)
+            p.vcycle(2, 2, kind, omega=omega, nu_coarse=nuc)
+            res.append(p.download(0, _lib.SLOT_V, 0))
+            res.append(p.download(2, _lib.SLOT_F, 0))
+        outs.append(res)
+        p.set_option(_lib.OPT_FUSED_ROWS, 0)
+        p.close()
+    for other in outs[:-1]:
+        for a, b in zip(other, outs[-1]):
+            assert rel_err(a, b) < 1e-11
+    S, SM = RefSolver(), RefStencilMaker()
+    smo = S.wjacobi if kind == _lib.WJACOBI else (lambda v, f, A, nu=4: S.gseidel_mc(v, f, A, nu=nu, dimension="2d"))
+    y = S.vcycle(v0, f, op.tocsr(), SM, nu1=2, nu2=2, smoother=smo, shift=0.45, lowest_level=8, dimension="2d")
+    p = Plan(op, 8, nvec=1)
+    p.set_shifts([0.45])
+    p.upload(0, _lib.SLOT_V, 0, v0)
+    p.upload(0, _lib.SLOT_F, 0, f)
+    p.vcycle(2, 2, kind, omega=omega, nu_coarse=4)                 # the oracle runs V(4,4) below the top level (reference quirk)
+    x = p.download(0, _lib.SLOT_V, 0)
+    p.close()
+    assert rel_err(x, y) < 1e-10
+
+
+@pytest.mark.parametrize("kind,omega", [(_lib.WJACOBI, 2. / 3.), (_lib.GS_MC, 1.0)])
 def test_recompute_instead_of_store_is_exact(backend, kind, omega):
     """MGCMT_OPT_RECOMPUTE: the down-leg pass skips storing the pre-smoothed iterate and the up-leg pass re-runs the
     same sweeps before adding the correction — the same arithmetic, so the cycle's result is bit-identical."""
@@ -178,9 +242,75 @@ def test_recompute_instead_of_store_is_exact(backend, kind, omega):
         assert np.array_equal(outs[0], outs[1]), (nu1, nu2, nuc)
 
 
+@pytest.mark.parametrize("kind,omega", [(_lib.WJACOBI, 2. / 3.), (_lib.GS_MC, 1.0), (_lib.GS_LEX, 1.0)])
+def test_zero_start_flag_equals_cleared_iterate(backend, kind, omega):
+    """MGCMT_CYCLE_ZERO_START (the reference's eigen-drivers start every cycle from zeros, 1DPotMatrixVcycle.py:70): the
+    cycle takes "V is zero" as a flag — V, here full of garbage, is neither read nor cleared first — and gives the bits
+    of a cycle on a cleared V; with and without recompute-instead-of-store, one and several columns, graph replay
+    included (three calls), and from a coarser start level."""
+    from multigridcmt_amd.operators import potential_well_operator
+    for g, make in ((128, lambda g: laplacian_operator(g, "2d") * SCALE), (64, lambda g: potential_well_operator(g, 50.0, (g // 4, 3 * g // 4)))):
+        op = make(g)
+        rng = np.random.RandomState(5)
+        for k, rec, level, nus in ((1, 2, 0, (2, 2, 2)), (2, 0, 0, (1, 3, 4)), (1, 2, 1, (2, 1, 2)), (1, 1, 0, (0, 2, 2))):
+            n = (g >> level) ** 2
+            f = rng.rand(k, n)
+            outs = []
+            for flagged in (True, False):
+                p = Plan(op, 8, nvec=k)
+                p.set_option(_lib.OPT_RECOMPUTE, rec)
+                p.set_shifts(0.3 + 0.1 * np.arange(k))
+                for q in range(k):
+                    p.upload(level, _lib.SLOT_F, q, f[q])
+                res = []
+                for _ in range(3):
+                    for q in range(k):
+                        if flagged:
+                            p.upload(level, _lib.SLOT_V, q, rng.rand(n) * 1e3)       # garbage the cycle must not see
+                        else:
+                            p.zero(level, _lib.SLOT_V, q)
+                    p.vcycle(nus[0], nus[1], kind, omega=omega, k=k, nu_coarse=nus[2], level=level, zero_start=flagged)
+                    res.append(np.stack([p.download(level, _lib.SLOT_V, q) for q in range(k)]))
+                p.close()
+                outs.append(res)
+            for a, b in zip(*outs):
+                assert np.array_equal(a, b), (g, k, rec, level, nus)
+
+
+def test_marching_apply_against_assembled_matrix(backend):
+    """mgcmt_apply on a finest 2-D level with a 5-point operator runs as a row march (k_apply_march: the scaled Laplacian
+    of MGCMTStencilMaker.py:15-25 and the square-well Hamiltonian, a product potential on its diagonal) — against the
+    assembled sparse matrix, with and without shifts, several columns, grids down to 2 x 2 and a chunk that ends inside
+    the grid (40 rows)."""
+    from multigridcmt_amd.operators import potential_well_operator
+    rng = np.random.RandomState(11)
+    for g, lowest in ((2, 2), (4, 2), (8, 8), (64, 8), (128, 8)):
+        for make in (lambda g: laplacian_operator(g, "2d") * SCALE, lambda g: potential_well_operator(g, 37.0, (g // 4, 3 * g // 4))):
+            op = make(g)
+            A = op.tocsr()
+            k = 3
+            p = Plan(op, lowest, nvec=k)
+            shifts = np.array([0.0, 0.7, -1.3])
+            p.set_shifts(shifts)
+            x = rng.rand(k, g * g) - 0.5
+            for q in range(k):
+                p.upload(0, _lib.SLOT_V, q, x[q])
+            for q in range(k):
+                for with_shift in (False, True):
+                    p.apply(0, (_lib.SLOT_V, q), (_lib.SLOT_W, q), with_shift=with_shift)
+                    want = A @ x[q] - (shifts[q] if with_shift else 0.0) * x[q]      # the shift of the source column
+                    assert rel_err(p.download(0, _lib.SLOT_W, q), want) < 1e-14, (g, q, with_shift)
+            rq, res = p.rayleigh_residual(0, _lib.SLOT_V, k)
+            for q in range(k):
+                ax = A @ x[q]
+                assert abs(rq[q] - x[q] @ ax / (x[q] @ x[q])) < 1e-12 * abs(rq[q])
+                assert abs(res[q] - np.linalg.norm(ax - shifts[q] * x[q])) < 1e-12 * res[q]
+            p.close()
+
+
 def test_potential_well_operator_three_terms(backend):
-    """BASELINE config 5's operator: -laplacian/pi^2 + square-well potential = three Kronecker terms (Op9<3> on every
-    level).  Fused vs one-launch-per-operation kernels, and the sparse oracle on the assembled matrix."""
+    """BASELINE config 5's operator: -laplacian/pi^2 + square-well potential = three Kronecker terms (a 5-point operator
+    with a product potential on the finest level, a constant 9-point part plus one variable term — Op9cv — below).  Fused vs one-launch-per-operation kernels, and the sparse oracle on the assembled matrix."""
     from multigridcmt_amd.operators import potential_well_operator
     from oracle.sparse_ref import RefSolver, RefStencilMaker
     g = 128
@@ -193,9 +323,13 @@ def test_potential_well_operator_three_terms(backend):
     v0, f = rng.rand(g * g), rng.rand(g * g)
     S, SM = RefSolver(), RefStencilMaker()
     # the finest level is a 5-point operator with a product potential (two-colour Gauss-Seidel, recompute allowed),
-    # its Galerkin coarsenings are general three-term 9-point operators (four colours)
+    # its Galerkin coarsenings are 9-point operators with a constant part and one variable term (four colours)
     p = Plan(op, 8, nvec=1)
     assert p.fused_max_recompute(0, _lib.GS_MC, 2) == 2 and p.fused_max_recompute(1, _lib.GS_MC, 2) == 0
+    assert [p.operator_kind(l) for l in range(4)] == [_lib.OPK_FIVE_DIAG] + [_lib.OPK_NINE_VAR] * 3
+    p.close()
+    p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
+    assert [p.operator_kind(l) for l in range(3)] == [_lib.OPK_FIVE_POINT, _lib.OPK_NINE_CONST, _lib.OPK_NINE_CONST]
     p.close()
     for kind, omega, smo in ((_lib.WJACOBI, 2. / 3., S.wjacobi),
                              (_lib.GS_MC, 1.0, lambda v, f, A, nu=4: S.gseidel_mc(v, f, A, nu=nu, dimension="2d"))):
