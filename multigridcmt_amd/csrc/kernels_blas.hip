@@ -342,6 +342,28 @@ struct BlockCombineArgs {
   double* out[kBlockMaxB];
   double c[kBlockMaxA][kBlockMaxB];
 };
+// 16-byte form (n even, every pointer 16-byte aligned): two elements per thread and access
+__global__ void k_block_combine2(long n2, BlockCombineArgs a, int nin, int nout) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+    double2 acc[kBlockMaxB];
+#pragma unroll
+    for (int j = 0; j < kBlockMaxB; ++j) acc[j] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int t = 0; t < kBlockMaxA; ++t) {
+      if (t < nin) {
+        const double2 x = reinterpret_cast<const double2*>(a.in[t])[i];
+#pragma unroll
+        for (int j = 0; j < kBlockMaxB; ++j) {
+          acc[j].x = fma(a.c[t][j], x.x, acc[j].x);
+          acc[j].y = fma(a.c[t][j], x.y, acc[j].y);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kBlockMaxB; ++j)
+      if (j < nout) reinterpret_cast<double2*>(a.out[j])[i] = acc[j];
+  }
+}
 // (an output may be one of the inputs: a thread reads all inputs of an element before it writes any output of it)
 __global__ void k_block_combine(long n, BlockCombineArgs a, int nin, int nout) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -553,6 +575,13 @@ void launch_block_combine(hipStream_t s, long n, const double* const* in, int ni
     for (int j = 0; j < kBlockMaxB; ++j) a.c[t][j] = (t < nin && j < nout) ? c[t * nout + j] : 0.0;
   }
   for (int j = 0; j < kBlockMaxB; ++j) a.out[j] = out[j < nout ? j : 0];
+  uintptr_t bits = (uintptr_t)(n & 1);
+  for (int t = 0; t < nin; ++t) bits |= reinterpret_cast<uintptr_t>(in[t]) & 15;
+  for (int j = 0; j < nout; ++j) bits |= reinterpret_cast<uintptr_t>(out[j]) & 15;
+  if (bits == 0) {
+    hipLaunchKernelGGL(k_block_combine2, dim3(blocks_for(n / 2)), dim3(256), 0, s, n / 2, a, nin, nout);
+    return;
+  }
   hipLaunchKernelGGL(k_block_combine, dim3(blocks_for(n)), dim3(256), 0, s, n, a, nin, nout);
 }
 

@@ -121,6 +121,71 @@ __global__ void __launch_bounds__(256) k_apply_march(KGrid g, KOp op, KVec src, 
   }
 }
 
+// The same march for any operator sum_m X_m (x) Y_m of a 2-D level (Galerkin operators R*A*P and mass operators R*M*P
+// of the Rayleigh-quotient multigrid, MGCMTSolver.py:99-122 — six applications per rqmin step and level): the factors
+// of the thread's two columns in registers, the row's factors by wave-uniform loads, the 3 x 4 neighbourhood in a
+// rotating register window.  The expressions are eval_point's, term by term, so the values are k_apply's bit for bit.
+template <int M>
+__global__ void __launch_bounds__(256) k_apply_march_terms(KGrid g, KOp op, KVec src, KVec dst, const double* __restrict__ shifts) {
+  const long j = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  if (j >= g.nc) return;
+  const int q = blockIdx.z;
+  const long nc = g.nc;
+  const long i0 = (long)blockIdx.y * kApplyRows;
+  const long i1 = i0 + kApplyRows < g.nr ? i0 + kApplyRows : g.nr;
+  const double mu = shifts ? shifts[q] : 0.0;
+  const double* __restrict__ v = src.p + q * src.stride;
+  double* __restrict__ out = dst.p + q * dst.stride;
+  const bool hw = j > 0, he = j + 2 < nc;
+  const long jw = hw ? j - 1 : j, je = he ? j + 2 : j + 1;
+  double yl[M][2], yd[M][2], yu[M][2];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const double* Y = op.Y[m] + j + c;
+      yl[m][c] = Y[0];
+      yd[m][c] = Y[op.ldy];
+      yu[m][c] = Y[2 * op.ldy];
+    }
+  struct Row4 {
+    double w, a, b, e;  // columns j-1, j, j+1, j+2 (zero outside the grid)
+  };
+  auto load4 = [&](long i) {
+    const double2 c = *reinterpret_cast<const double2*>(v + i * nc + j);
+    const double w = v[i * nc + jw], e = v[i * nc + je];
+    return Row4{hw ? w : 0.0, c.x, c.y, he ? e : 0.0};
+  };
+  Row4 n = load4(i0 - 1), c = load4(i0);  // row -1 / nr: halo rows (zeros at the global boundary, a neighbour strip's rows otherwise)
+#pragma unroll 2
+  for (long i = i0; i < i1; ++i) {
+    const Row4 s = load4(i + 1);
+    double offa = 0.0, offb = 0.0, da = 0.0, db = 0.0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const double* X = op.X[m] + i;
+      const double xl = X[0], xd = X[op.ldx], xu = X[2 * op.ldx];
+      {
+        const double rn = yl[m][0] * n.w + yd[m][0] * n.a + yu[m][0] * n.b;
+        const double rc = yl[m][0] * c.w + yu[m][0] * c.b;
+        const double rs = yl[m][0] * s.w + yd[m][0] * s.a + yu[m][0] * s.b;
+        offa += xl * rn + xd * rc + xu * rs;
+        da += xd * yd[m][0];
+      }
+      {
+        const double rn = yl[m][1] * n.a + yd[m][1] * n.b + yu[m][1] * n.e;
+        const double rc = yl[m][1] * c.a + yu[m][1] * c.e;
+        const double rs = yl[m][1] * s.a + yd[m][1] * s.b + yu[m][1] * s.e;
+        offb += xl * rn + xd * rc + xu * rs;
+        db += xd * yd[m][1];
+      }
+    }
+    *reinterpret_cast<double2*>(out + i * nc + j) = make_double2(offa + (da - mu) * c.a, offb + (db - mu) * c.b);
+    n = c;
+    c = s;
+  }
+}
+
 // weighted Jacobi, out of place:  v' = v + w (f - (A - mu I) v) / d     (MGCMTSolver.py:193-206)
 __global__ void k_wjacobi(KGrid g, KOp op, KVec vin, KVec f, KVec vout, const double* __restrict__ shifts, double omega) {
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -236,6 +301,17 @@ void launch_apply(hipStream_t s, KGrid g, KOp op, KVec src, KVec dst, const doub
     if (op.five_point) hipLaunchKernelGGL(k_apply_march<0>, grid, b, 0, s, g, op, src, dst, shifts);
     else if (op.ndiag == 1) hipLaunchKernelGGL(k_apply_march<1>, grid, b, 0, s, g, op, src, dst, shifts);
     else hipLaunchKernelGGL(k_apply_march<2>, grid, b, 0, s, g, op, src, dst, shifts);
+    return;
+  }
+  if (g.coarsen_rows && g.nr >= 2 && g.nc >= 2 && (g.nc & 1) == 0 && aligned && op.nterms >= 1 && op.nterms <= 4 && !op.five_diag) {
+    const dim3 b(g.nc >= 512 ? 256 : 64, 1, 1);
+    const dim3 grid((unsigned)((g.nc / 2 + b.x - 1) / b.x), (unsigned)((g.nr + kApplyRows - 1) / kApplyRows), (unsigned)k);
+    switch (op.nterms) {
+      case 1: hipLaunchKernelGGL(k_apply_march_terms<1>, grid, b, 0, s, g, op, src, dst, shifts); break;
+      case 2: hipLaunchKernelGGL(k_apply_march_terms<2>, grid, b, 0, s, g, op, src, dst, shifts); break;
+      case 3: hipLaunchKernelGGL(k_apply_march_terms<3>, grid, b, 0, s, g, op, src, dst, shifts); break;
+      default: hipLaunchKernelGGL(k_apply_march_terms<4>, grid, b, 0, s, g, op, src, dst, shifts); break;
+    }
     return;
   }
   const dim3 b = block_for(g.nr);

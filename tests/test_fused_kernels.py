@@ -308,6 +308,47 @@ def test_marching_apply_against_assembled_matrix(backend):
             p.close()
 
 
+def test_marching_apply_on_galerkin_levels(backend):
+    """mgcmt_apply on the coarser levels (k_apply_march_terms: any sum of Kronecker terms) — operator A and mass operator
+    M, the six applications per step and level of the reference's Rayleigh-quotient multigrid (MGCMTSolver.py:17-57,
+    :99-122) — against R*A*P / R*M*P assembled from the stencil maker's matrices (MGCMTSolver.py:318) for a constant
+    operator, the square well, an operator with three variable terms and the Mehrstellen pair."""
+    from multigridcmt_amd.operators import (StructuredOperator, identity_operator, mehrstellen_mass, mehrstellen_operator,
+                                            potential_well_operator, tri_identity, tri_laplacian)
+    from multigridcmt_amd.stencil_maker import MGCMTStencilMaker
+    SM = MGCMTStencilMaker()
+    g = 64
+    rng = np.random.RandomState(29)
+    Lx, Ly = tri_laplacian(g) * SCALE, tri_laplacian(g) * SCALE
+    Lx[1] += 3.0 * rng.rand(g)
+    Ly[1] += 3.0 * rng.rand(g)
+    dp, dq = np.zeros((3, g)), np.zeros((3, g))
+    dp[1], dq[1] = 1.0 + rng.rand(g), 0.5 + rng.rand(g)
+    cases = [(laplacian_operator(g, "2d") * SCALE, identity_operator(g, "2d"), _lib.OPK_NINE_CONST),
+             (potential_well_operator(g, 30.0, (g // 4, 3 * g // 4)), identity_operator(g, "2d"), _lib.OPK_NINE_VAR),
+             (StructuredOperator("2d", g, [(tri_identity(g), Ly), (Lx, tri_identity(g)), (dp, dq)]), identity_operator(g, "2d"), _lib.OPK_GENERAL),
+             (mehrstellen_operator(g), mehrstellen_mass(g), _lib.OPK_NINE_CONST)]
+    for op, mass, kind1 in cases:
+        p = Plan(op, 8, nvec=2, mass=mass)
+        p.set_shifts([0.0, 0.9])
+        assert p.operator_kind(1) == kind1
+        A, M = op.tocsr(), mass.tocsr()
+        for level in (0, 1, 2):
+            gl = g >> level
+            if level > 0:
+                R, P = SM.restriction(2 * gl, gl, dimension="2d"), SM.interpolation(gl, 2 * gl, dimension="2d")
+                A, M = (R @ A @ P).tocsr(), (R @ M @ P).tocsr()
+            x = rng.rand(2, gl * gl) - 0.5
+            for q in range(2):
+                p.upload(level, _lib.SLOT_V, q, x[q])
+            for q in range(2):
+                p.apply(level, (_lib.SLOT_V, q), (_lib.SLOT_W, q), with_shift=True)
+                assert rel_err(p.download(level, _lib.SLOT_W, q), A @ x[q] - (0.9 if q else 0.0) * x[q]) < 1e-13, (kind1, level, q)
+                p.apply(level, (_lib.SLOT_V, q), (_lib.SLOT_W, q), op=_lib.OP_M)
+                assert rel_err(p.download(level, _lib.SLOT_W, q), M @ x[q]) < 1e-13, (kind1, level, q)
+        p.close()
+
+
 def test_potential_well_operator_three_terms(backend):
     """BASELINE config 5's operator: -laplacian/pi^2 + square-well potential = three Kronecker terms (a 5-point operator
     with a product potential on the finest level, a constant 9-point part plus one variable term — Op9cv — below).  Fused vs one-launch-per-operation kernels, and the sparse oracle on the assembled matrix."""
