@@ -337,6 +337,45 @@ def main(argv=None):
             big.close()
         except Exception as e:                                  # e.g. a smaller-memory device
             out["strong_scaling_base"] = {"value": None, "error": str(e)}
+    if not args.no_extras and g == 16384:
+        # BASELINE configs 2 and 5 in the same line (their own bench commands: `--config 1`, scripts/bench_config5.py)
+        try:
+            g2 = 4096
+            c2 = Plan(laplacian_operator(g2, "2d") * (-1.0 / np.pi ** 2), args.lowest, nvec=1, device=0)
+            c2.set_shifts([0.0])
+            c2.upload(0, _lib.SLOT_F, 0, f[:g2 * g2])
+            c2.fill(0, _lib.SLOT_V, 0, 0.0)
+            t = time_cycles(c2, 40, 5, lambda: c2.vcycle(2, 2, _lib.GS_MC, omega=1.0, k=1, nu_coarse=2))
+            out["config2_4096_redblack"] = {"workload": "2D Laplacian 4096^2 fp64, V(2,2) red-black Gauss-Seidel, 1xMI355X",
+                                            "ms_per_step": t / 40 * 1e3, "vcycles_per_s": 40 / t,
+                                            "value": float(g2) * g2 * 4 * 40 / t / 1e6, "unit": "MLUPS"}
+            c2.close()
+        except Exception as e:
+            out["config2_4096_redblack"] = {"value": None, "error": str(e)}
+        try:
+            from multigridcmt_amd import drivers
+            from multigridcmt_amd.operators import potential_well_operator
+            g5 = 8192
+            rec = {"workload": "2D square-well Hamiltonian %d^2 fp64 (PotWellSolver.py:150-153 carried to 2-D): V(2,2) cycle of H; "
+                               "Rayleigh-quotient minimisation with that cycle as the preconditioner, 1xMI355X" % g5}
+            w5 = Plan(potential_well_operator(g5, 50.0, (g5 // 4, 3 * g5 // 4)), args.lowest, nvec=1, device=0)
+            w5.set_shifts([0.0])
+            w5.upload(0, _lib.SLOT_F, 0, f[:g5 * g5])
+            for name_, (k_, om_) in (("wjacobi", kinds["wjacobi"]), ("redblack", kinds["rb"])):
+                w5.fill(0, _lib.SLOT_V, 0, 0.0)
+                t = time_cycles(w5, 10, 3, lambda: w5.vcycle(2, 2, k_, omega=om_, k=1, nu_coarse=2))
+                rec["vcycle_%s_ms_per_step" % name_] = t / 10 * 1e3
+            w5.close()
+            drivers.potential_well_eigensolve(g5, cycles=2, method="vcycle")            # plan, graph capture
+            stats, hist = {}, []
+            drivers.potential_well_eigensolve(g5, cycles=10, method="vcycle", stats=stats, history=hist)
+            rec["eigen_iteration_ms"] = stats["loop_seconds"] / 10 * 1e3
+            rec["rayleigh_quotient_history"] = hist
+            out["config5_8192_square_well"] = rec
+            from multigridcmt_amd.plan import release_plans
+            release_plans()
+        except Exception as e:
+            out["config5_8192_square_well"] = {"value": None, "error": str(e)}
     del f
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.smoother)

@@ -1,0 +1,13 @@
+# session 2: apply march + Op9cv — GPU suite, config 5, cycle sanity (Laplacian unchanged), eigen-iteration kernel mix
+set -x
+mkdir -p gpurun_out
+TAG=${1:-s2d}
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_$TAG.log
+tail -4 gpurun_out/pytest_gpu_$TAG.log
+timeout -k 10 300 python scripts/bench_config5.py > gpurun_out/cfg5_$TAG.json 2>&1; cat gpurun_out/cfg5_$TAG.json
+rm -f variants/*.so
+timeout -k 10 300 python scripts/tune_cycles.py > gpurun_out/cycles_$TAG.log 2>&1; cat gpurun_out/cycles_$TAG.log
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_eigen -- python3 $GRAFT_REPO_ROOT/scripts/prof_eigen_iteration.py > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_eigen.log 2>&1
+grep ms_per_iteration $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_eigen.log
+find $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_eigen -name "*kernel_stats.csv" | head -1 | xargs -r head -12
