@@ -552,6 +552,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   const int r_end = r_begin + a.rows_per_chunk < a.out_hi ? r_begin + a.rows_per_chunk : a.out_hi;
   const int rstart = r_begin - (S + E);
   const int rstop = r_end + S + XL + 2 * E;  // rows [rstart, rstop) are marched over
+  // Dependency cone of the chunk's outputs: stage s is only NEEDED on rows >= cone0 + s (its products on the rows
+  // before that feed nothing the chunk stores — the march starts S + E rows early for stage 0's sake, and the later a
+  // stage, the more of those early rows it can skip: S^2 stage-rows per chunk, more than the useful ones on the short
+  // chunks of small levels).  The end of the march needs no such test: it stops when the last stage is done.
+  const int cone0 = r_begin - (S - 1) - (RESTRICT ? 1 : 0);
 
   auto row_ok = [&](int row) { return row >= row_lo && row < row_hi; };
 
@@ -754,7 +759,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
             upd_b = row_on && ccb == 1;
           }
           // wave-uniform; outside the grid (a few steps of the first and last chunks) the value stays zero
-          if ((upd_a || upd_b) && (!CHK || ((okbits >> lag) & 1u) != 0)) {
+          if ((upd_a || upd_b) && (!CHK || (((okbits >> lag) & 1u) != 0 && rs >= cone0 + s))) {
             op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
             if (upd_a) {
               double off, dg, inv;
@@ -788,7 +793,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
         } else {
           // residual of row rs and its full-weighting restriction
           double ra = 0.0, rb = 0.0;
-          if (!CHK || ((okbits >> lag) & 1u) != 0) {
+          if (!CHK || (((okbits >> lag) & 1u) != 0 && rs >= r_begin)) {
             op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
             double offa, offb, dga, dgb, inva, invb;
             eval_a(offa, dga, inva);
@@ -867,7 +872,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
           }
           double na = ca, nb = cb;
           // wave-uniform; outside the grid (a few steps of the first and last chunks) the value stays zero
-          if ((upd_a || upd_b) && (!CHK || ((okbits >> (s + 1)) & 1u) != 0)) {
+          if ((upd_a || upd_b) && (!CHK || (((okbits >> (s + 1)) & 1u) != 0 && rs >= cone0 + s))) {
             op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
             if (upd_a) {
               double off, dg, inv;
@@ -890,7 +895,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
         } else {
           // residual of row rs and its full-weighting restriction
           double ra = 0.0, rb = 0.0;
-          if (!CHK || ((okbits >> (s + 1)) & 1u) != 0) {
+          if (!CHK || (((okbits >> (s + 1)) & 1u) != 0 && rs >= r_begin)) {
             op.set_row(a, rs, ring + (rs & (kRing - 1)) * RV);
             double offa, offb, dga, dgb, inva, invb;
             eval_a(offa, dga, inva);

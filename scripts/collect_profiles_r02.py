@@ -33,9 +33,19 @@ def short(name):
     return name.split("(")[0]
 
 
-def waves_per_simd(vgprs):
-    alloc = -(-int(vgprs) // 8) * 8
-    return max(1, min(8, 512 // max(alloc, 1)))
+# The kernel-trace CSV's VGPR_Count is HALF the allocation on this stack: for k_fused<Op9c, 0, 2, 14> the compiler's own
+# .vgpr_count / "; Occupancy" say 117 registers, 4 waves per SIMD (hipcc -S --cuda-device-only of kernels_fused_op9c.hip),
+# the trace says 60; the same factor holds for every kernel compared (Op5 plain pass 104 vs 52, red-black up-leg pass
+# 216 vs 108).  The table carries the allocation (2 x the traced value) and the waves per SIMD that follow from it.
+TRACE_VGPR_FACTOR = 2
+
+
+def vgpr_alloc(traced):
+    return -(-int(traced) * TRACE_VGPR_FACTOR // 8) * 8
+
+
+def waves_per_simd(traced):
+    return max(1, min(8, 512 // max(vgpr_alloc(traced), 1)))
 
 
 def clusters(values, ratio=0.62):
@@ -109,7 +119,7 @@ for sm in ("wjacobi", "rb"):
         valu = (100.0 * k["SQ_ACTIVE_INST_VALU"] / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None
         wait = (100.0 * k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None
         label = short(kname) + (" [size class %d]" % lev if "k_fused" in kname else "")
-        table_rows.append((sm, label, k["calls"], avg_us, k["vgpr"], waves_per_simd(k["vgpr"]) if k["vgpr"] else None, valu, wait,
+        table_rows.append((sm, label, k["calls"], avg_us, vgpr_alloc(k["vgpr"]) if k["vgpr"] else None, waves_per_simd(k["vgpr"]) if k["vgpr"] else None, valu, wait,
                            hbm, (hbm / (avg_us * 1e-6) / 1e12) if hbm else None))
         if hbm is not None:
             detail["%s_%d %s" % (sm, n, label)] = {"avg_us": avg_us, "FETCH_SIZE_KB_avg": fetch, "WRITE_SIZE_KB_avg": write,
@@ -143,8 +153,9 @@ if traffic:
     json.dump(detail, open(os.path.join(out, "%s_pmc_traffic_detail.json" % prefix), "w"), indent=1)
 with open(os.path.join(out, "%s_kernel_table.md" % prefix), "w") as fh:
     fh.write("# Per-kernel table of the 16384^2 V(2,2) cycles (run tag %s, commit %s)\n\n" % (tag, commit))
-    fh.write("rocprofv3 kernel trace + PMC passes of `bench.py --smoother <sm>` (scripts/gpu_r02_profiles.sh).  waves/SIMD = what the VGPR\n"
-             "allocation admits (MI355X_MICROARCH.md, Register files); VALU %% = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, wait %% = SQ_WAIT_ANY /\n"
+    fh.write("rocprofv3 kernel trace + PMC passes of `bench.py --smoother <sm>` (scripts/gpu_r02_profiles.sh).  VGPRs = the allocation (2 x the trace's\n"
+             "VGPR_Count, which is half the compiler's .vgpr_count on this stack: checked against hipcc -S), waves/SIMD = what that allocation admits\n"
+             "(MI355X_MICROARCH.md, Register files); VALU %% = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, wait %% = SQ_WAIT_ANY /\n"
              "SQ_WAVE_CYCLES (both per wave); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE per launch; TB/s = those bytes / average launch time.\n"
              "One instantiation runs on several levels; \"size class\" groups its dispatches by size (0 = the largest level it runs on: Op5 =\n16384^2, Op9c = 8192^2; every class is about four times fewer points; the smallest classes are merged).\nTemplate arguments of k_fused: <operator policy, smoother (0 Jacobi, 1 red-black, 2 four-colour), sweeps, flags (1 prolong, 2 restrict,\n4 zero-in, 8 no-store, 16/32 recomputed sweeps)>.\n\n")
     fh.write("| cycle | kernel | launches | avg us | VGPRs | waves/SIMD | VALU % | wait % | HBM MB/launch | TB/s |\n|---|---|---|---|---|---|---|---|---|---|\n")
