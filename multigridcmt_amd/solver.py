@@ -25,6 +25,19 @@ def _is_pow2(x):
     return x > 0 and (x & (x - 1)) == 0
 
 
+def _all_zero(a):
+    """True when every entry of `a` is zero.  A handful of samples settles the usual non-zero start vector at no cost
+    (a full scan of a 0.5 GB iterate costs more than its transfer); only when they are all zero is the array scanned."""
+    flat = a.ravel(order="K")                  # a view of contiguous arrays, whatever their order
+    n = flat.size
+    if n == 0:
+        return True
+    step = max(1, n // 61)
+    if flat[::step].any() or flat[-1] != 0:
+        return False
+    return not flat.any()
+
+
 def _force_column(a, n):
     """The reference sets ``.shape = (n, 1)`` on the CALLER's arrays (MGCMTSolver.py:187-191,297-300)."""
     if isinstance(a, np.ndarray) and a.shape != (n, 1):
@@ -268,7 +281,7 @@ class MGCMTSolver:
         plan = get_plan(op, int(lowest_level), nvec=1)
         plan.set_shifts([float(shift)])
         v0 = np.asarray(v0, dtype=np.float64).reshape(-1)
-        zero_start = not v0.any()                 # a zero start vector (the reference's drivers) is a flag, not a transfer
+        zero_start = _all_zero(v0)                # a zero start vector (the reference's drivers) is a flag, not a transfer
         if not zero_start:
             plan.upload(0, SLOT_V, 0, v0)
         elif kind is None:
@@ -364,7 +377,7 @@ class MGCMTSolver:
         op = recognise(A, dimension)
         plan = get_plan(op, int(lowest_level), nvec=k)
         plan.set_shifts(shifts)
-        zero_start = not v0_matrix.any()          # the reference's callers pass zeros (1DPotMatrixVcycle.py:70): nothing to upload
+        zero_start = _all_zero(v0_matrix)         # the reference's callers pass zeros (1DPotMatrixVcycle.py:70): nothing to upload
         for i in range(k):
             if not zero_start:
                 plan.upload(0, SLOT_V, i, v0_matrix[:, i])
