@@ -487,7 +487,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // (Asking the compiler for more waves per SIMD through the second launch-bound argument was measured: with 3 or 4 it
-// spills the windows to scratch and the cycle takes 2-3x as long.  The register counts it picks on its own are right.)
+// spills the windows to scratch and the cycle takes 2-3x as long.  Second session, with the real allocations known
+// (§4.1 of DESIGN.md): the four-colour 9-point passes sit at 176 - 184 registers = 2 waves per SIMD, and asked for 3
+// they come out at 168 with 12 registers spilled — 8192^2 pass 0.306 -> 0.341 ms, 4096^2 red-black cycle 0.402 ->
+// 0.474 ms.  The register counts the compiler picks on its own are right.)
 template <class OP, int KIND, int NSWEEP, int FLAGS>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   using Shape = FusedShape<OP, KIND, NSWEEP, FLAGS>;
