@@ -19,7 +19,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, g, kind, omega, nu, out_dir, force_recompute):
+def _operator(name, g):
+    from multigridcmt_amd.operators import laplacian_operator, potential_well_operator
+    if name == "well":        # BASELINE config 5's Hamiltonian: 5-point + product potential on the strips of the finest level,
+        return potential_well_operator(g, 40.0, (g // 4, 3 * g // 4))     # constant part + one variable term below it
+    return laplacian_operator(g, "2d") * (-1 / np.pi ** 2)
+
+
+def _worker(rank, world, port, g, kind, omega, nu, out_dir, force_recompute, opname="laplacian"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hip_cpu_mock")):
@@ -30,9 +37,8 @@ def _worker(rank, world, port, g, kind, omega, nu, out_dir, force_recompute):
     from multigridcmt_amd import _lib
     _lib.use_library(build_emu.build())
     from multigridcmt_amd.distributed import ShardedPlan
-    from multigridcmt_amd.operators import laplacian_operator
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    op = laplacian_operator(g, "2d") * (-1 / np.pi ** 2)
+    op = _operator(opname, g)
     sp = ShardedPlan(op, 8, rank, world, switch_grid=g // 4, on_gpu=False)
     sp.set_shift(0.4)
     sp.set_comm_option(_lib.COMM_OPT_SPLIT, 2)      # boundary rows first on these small strips too
@@ -70,6 +76,41 @@ def test_sharded_cycle_equals_single_plan(tmp_path, world, kind_name, force_reco
     res, strip_levels = np.load(tmp_path / "res.npy")
     assert strip_levels == 2
     p = Plan(laplacian_operator(g, "2d") * (-1 / np.pi ** 2), 8, nvec=1)
+    p.set_shifts([0.4])
+    rng = np.random.RandomState(5)
+    f, v0 = rng.rand(g * g), rng.rand(g * g)
+    p.upload(0, _lib.SLOT_F, 0, f)
+    p.upload(0, _lib.SLOT_V, 0, v0)
+    for _ in range(2):
+        p.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu)
+    want = p.download(0, _lib.SLOT_V, 0)
+    p.apply(0, (_lib.SLOT_V, 0), (_lib.SLOT_T, 0), with_shift=True)
+    p.axpy(0, -1.0, (_lib.SLOT_F, 0), (_lib.SLOT_T, 0))
+    want_res = np.sqrt(p.dot(0, (_lib.SLOT_T, 0), (_lib.SLOT_T, 0)))
+    p.close()
+    assert rel_err(got, want) < 1e-12
+    assert abs(res - want_res) < 1e-9 * want_res
+
+
+@pytest.mark.parametrize("kind_name", ["wjacobi", "rb"])
+def test_sharded_square_well_equals_single_plan(tmp_path, kind_name):
+    """The same on the square-well Hamiltonian (BASELINE config 5's operator): the strips of the finest level run the
+    5-point-plus-product-potential passes, the strips below it the constant-part-plus-variable-term passes, whose row
+    factors carry halo entries of the neighbours' rows; the residual norm goes through the marching operator
+    application on a strip."""
+    import torch.multiprocessing as mp
+    from conftest import bind_backend
+    bind_backend("emu")
+    from multigridcmt_amd import _lib
+    from multigridcmt_amd.plan import Plan
+    g, nu, world = 256, 2, 2
+    kind, omega = (_lib.WJACOBI, 2. / 3.) if kind_name == "wjacobi" else (_lib.GS_MC, 1.0)
+    mp.spawn(_worker, args=(world, _free_port(), g, kind, omega, nu, str(tmp_path), False, "well"), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("part%d.npy" % r)) for r in range(world)])
+    res, strip_levels = np.load(tmp_path / "res.npy")
+    assert strip_levels == 2
+    p = Plan(_operator("well", g), 8, nvec=1)
+    assert [p.operator_kind(l) for l in range(2)] == [_lib.OPK_FIVE_DIAG, _lib.OPK_NINE_VAR]
     p.set_shifts([0.4])
     rng = np.random.RandomState(5)
     f, v0 = rng.rand(g * g), rng.rand(g * g)
