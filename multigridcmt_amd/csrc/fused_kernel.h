@@ -1005,7 +1005,10 @@ void launch_one(hipStream_t s, FusedArgs a, int k) {
     long chunks = (long)(0.9 * resident_blocks) / (groups * k);
     if (chunks < 1) chunks = 1;
     rows = (nrows + chunks - 1) / chunks;
-    if (rows < kFusedMinRows) rows = kFusedMinRows;
+    // (second session: with the dependency-cone skip a Jacobi chunk of 2 rows beats 4 on small levels — 256^2 cycle 0.057 ->
+    // 0.053 ms, 1024^2 0.107 -> 0.104 —, the colour smoothers' longer pipelines still want 4: 4096^2 red-black 0.403 vs 0.412)
+    const long min_rows = (KIND == kJacobi && kFusedMinRows > 2) ? 2 : kFusedMinRows;
+    if (rows < min_rows) rows = min_rows;
   }
   if (rows > nrows) rows = nrows;
   rows = (rows + 1) & ~1L;
