@@ -327,7 +327,10 @@ def test_marching_apply_on_galerkin_levels(backend):
     cases = [(laplacian_operator(g, "2d") * SCALE, identity_operator(g, "2d"), _lib.OPK_NINE_CONST),
              (potential_well_operator(g, 30.0, (g // 4, 3 * g // 4)), identity_operator(g, "2d"), _lib.OPK_NINE_VAR),
              (StructuredOperator("2d", g, [(tri_identity(g), Ly), (Lx, tri_identity(g)), (dp, dq)]), identity_operator(g, "2d"), _lib.OPK_GENERAL),
-             (mehrstellen_operator(g), mehrstellen_mass(g), _lib.OPK_NINE_CONST)]
+             (mehrstellen_operator(g), mehrstellen_mass(g), _lib.OPK_NINE_CONST),
+             # four terms (the library's maximum): variable Laplacian terms, a product potential and a cross term
+             (StructuredOperator("2d", g, [(tri_identity(g), Ly), (Lx, tri_identity(g)), (dp, dq),
+                                           (tri_laplacian(g) * (1.0 / (6.0 * g * g)), tri_laplacian(g) * SCALE)]), identity_operator(g, "2d"), _lib.OPK_GENERAL)]
     for op, mass, kind1 in cases:
         p = Plan(op, 8, nvec=2, mass=mass)
         p.set_shifts([0.0, 0.9])
