@@ -21,11 +21,12 @@ def _case(rng, sizes):
     k = int(rng.randint(1, 4))
     well = bool(rng.randint(0, 3) == 0)
     opts = {_lib.OPT_RECOMPUTE: int(rng.choice([0, 1, 2])), _lib.OPT_TAIL: int(rng.randint(0, 2)), _lib.OPT_GRAPH: int(rng.randint(0, 2))}
-    return g, lowest, kind, omega, nu1, nu2, nuc, k, well, opts
+    zero_start = bool(rng.randint(0, 3) == 0)    # every cycle starts from "V is zero" as a flag (MGCMT_CYCLE_ZERO_START); V holds garbage
+    return g, lowest, kind, omega, nu1, nu2, nuc, k, well, opts, zero_start
 
 
 def _run_case(case, seed):
-    g, lowest, kind, omega, nu1, nu2, nuc, k, well, opts = case
+    g, lowest, kind, omega, nu1, nu2, nuc, k, well, opts, zero_start = case
     op = potential_well_operator(g, 20.0, (g // 4, 3 * g // 4)) if well else laplacian_operator(g, "2d") * (-1 / np.pi ** 2)
     rng = np.random.RandomState(seed)
     v0, f = rng.rand(k, g * g), rng.rand(k, g * g)
@@ -37,10 +38,10 @@ def _run_case(case, seed):
             p.set_option(o, val)
         p.set_shifts(0.2 + 0.5 * np.arange(k))
         for q in range(k):
-            p.upload(0, _lib.SLOT_V, q, v0[q])
+            p.upload(0, _lib.SLOT_V, q, v0[q] * (1e6 if zero_start else 1.0))
             p.upload(0, _lib.SLOT_F, q, f[q])
         for _ in range(3):                      # with graph replay from the second call on
-            p.vcycle(nu1, nu2, kind, omega=omega, k=k, nu_coarse=nuc)
+            p.vcycle(nu1, nu2, kind, omega=omega, k=k, nu_coarse=nuc, zero_start=zero_start)
         outs.append(np.stack([p.download(0, _lib.SLOT_V, q) for q in range(k)]))
         p.close()
     return rel_err(outs[0], outs[1])
