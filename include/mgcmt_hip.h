@@ -158,6 +158,13 @@ int mgcmt_gram(mgcmt_plan* plan, int level, int nv, const int* slots, const int*
  * k-column operator application (into slot W) and one reduction pass per column; ONE synchronisation for all of them.
  * Either output may be NULL. */
 int mgcmt_rayleigh_residual(mgcmt_plan* plan, int level, int slot, int k, double* rq_out, double* res_out, void* stream);
+/* The inner products of the 2 x 2 Rayleigh-Ritz problem on span{x, w} (rqmin's pencil, MGCMTSolver.py:44-50, when <x, A x>
+ * is known from the previous step): out5 = <x,x>, <x,w>, <w,w>, <x,A w>, <w,A w> with the UNSHIFTED operator of `level`.
+ * On 2-D levels with a 5-point operator (with or without a product potential) ONE pass reads x and w once and stores
+ * nothing; elsewhere A w goes to the scratch vector (mgcmt_apply) and one mgcmt_gram pass follows.  The scratch vector must
+ * differ from x and w.  Synchronises. */
+int mgcmt_ritz_pair(mgcmt_plan* plan, int level, int x_slot, int x_vec, int w_slot, int w_vec, int scratch_slot, int scratch_vec,
+                    double* out5, void* stream);
 /* dst = sum_t coeffs[t] * (slots[t], vecs[t]), 1 <= nterms <= 4; dst may be one of the inputs (the updates
  * x <- x + delta p, MGCMTSolver.py:52, and the residual A x - rho M x, :22-23, in one pass each) */
 int mgcmt_lincomb(mgcmt_plan* plan, int level, int nterms, const double* coeffs, const int* slots, const int* vecs, int dst_slot,

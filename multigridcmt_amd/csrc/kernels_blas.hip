@@ -526,6 +526,11 @@ int reduce_blocks(long n) {
   return (int)b;
 }
 
+// out[q] = sum of partials[q * nblocks .. (q + 1) * nblocks), q < nq (the second pass of a reduction whose first pass lives elsewhere)
+void launch_final_sums(hipStream_t s, int nq, int nblocks, const double* partials, double* out) {
+  hipLaunchKernelGGL(k_dot_final, dim3(nq), dim3(kRedThreads), 0, s, nblocks, partials, out);
+}
+
 // first pass only: partials[q*reduce_blocks(n) + b]
 void launch_dot_partials(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials) {
   hipLaunchKernelGGL(k_dot_partial, dim3(reduce_blocks(n), nq), dim3(kRedThreads), 0, s, n, x, y, ystride, partials);

@@ -121,6 +121,76 @@ __global__ void __launch_bounds__(256) k_apply_march(KGrid g, KOp op, KVec src, 
   }
 }
 
+// The five inner products of the 2 x 2 Rayleigh-Ritz problem on span{x, w} (MGCMTSolver.py:44-50 with <x, A x> known) in
+// ONE march over x and w: A w is formed in registers row by row as in k_apply_march and never stored.  Per block five
+// partial sums (fixed order: deterministic); launch_final_sums adds them up.
+template <int ND>
+__global__ void __launch_bounds__(256) k_ritz_march(KGrid g, KOp op, const double* __restrict__ x, const double* __restrict__ v, int rows,
+                                                   double* __restrict__ partials, int nblocks) {
+  __shared__ double s_part[5][4];
+  const long j = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  const long nc = g.nc;
+  const long i0 = (long)blockIdx.y * rows;
+  const long i1 = i0 + rows < g.nr ? i0 + rows : g.nr;
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  if (j < nc) {
+    const bool hw = j > 0, he = j + 2 < nc;
+    const long jw = hw ? j - 1 : j, je = he ? j + 2 : j + 1;
+    const double cn = op.cn, cw = op.cw, d0 = op.c0;
+    double qa[ND > 0 ? ND : 1], qb[ND > 0 ? ND : 1];
+#pragma unroll
+    for (int m = 0; m < ND; ++m) {
+      qa[m] = op.dY[m][j];
+      qb[m] = op.dY[m][j + 1];
+    }
+    auto row2 = [&](const double* p, long i) { return *reinterpret_cast<const double2*>(p + i * nc + j); };
+    double2 n = row2(v, i0 - 1), c = row2(v, i0);
+    double w = hw ? v[i0 * nc + jw] : 0.0, e = he ? v[i0 * nc + je] : 0.0;
+#pragma unroll 2
+    for (long i = i0; i < i1; ++i) {
+      const double2 sr = row2(v, i + 1);
+      const double2 xr = row2(x, i);
+      const double wn = v[(i + 1) * nc + jw], en = v[(i + 1) * nc + je];
+      double da = d0, db = d0;
+#pragma unroll
+      for (int m = 0; m < ND; ++m) {
+        const double pm = op.dX[m][i];
+        da += pm * qa[m];
+        db += pm * qb[m];
+      }
+      double ha = cw * (w + c.y), hb = cw * (c.x + e);
+      ha += cn * (n.x + sr.x);
+      hb += cn * (n.y + sr.y);
+      ha += da * c.x;
+      hb += db * c.y;
+      acc[0] += xr.x * xr.x + xr.y * xr.y;
+      acc[1] += xr.x * c.x + xr.y * c.y;
+      acc[2] += c.x * c.x + c.y * c.y;
+      acc[3] += xr.x * ha + xr.y * hb;
+      acc[4] += c.x * ha + c.y * hb;
+      n = c;
+      c = sr;
+      w = hw ? wn : 0.0;
+      e = he ? en : 0.0;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    double t = acc[q];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
+    if (lane == 0) s_part[q][wave] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    double t = 0.0;
+    const int nw = blockDim.x >> 6;
+    for (int k = 0; k < nw; ++k) t += s_part[threadIdx.x][k];
+    partials[(long)threadIdx.x * nblocks + (long)blockIdx.y * gridDim.x + blockIdx.x] = t;
+  }
+}
+
 // The same march for any operator sum_m X_m (x) Y_m of a 2-D level (Galerkin operators R*A*P and mass operators R*M*P
 // of the Rayleigh-quotient multigrid, MGCMTSolver.py:99-122 — six applications per rqmin step and level): the factors
 // of the thread's two columns in registers, the row's factors by wave-uniform loads, the 3 x 4 neighbourhood in a
@@ -316,6 +386,24 @@ void launch_apply(hipStream_t s, KGrid g, KOp op, KVec src, KVec dst, const doub
   }
   const dim3 b = block_for(g.nr);
   hipLaunchKernelGGL(k_apply, grid2d(g.nc, g.nr, k, b), b, 0, s, g, op, src, dst, shifts);
+}
+
+bool launch_ritz_pair(hipStream_t s, KGrid g, KOp op, const double* x, const double* w, double* partials, double* out) {
+  const bool aligned = (((uintptr_t)x | (uintptr_t)w) & 15) == 0;
+  if (!(g.coarsen_rows && g.nr >= 2 && g.nc >= 2 && (g.nc & 1) == 0 && aligned && ((op.five_point && op.cn != 0.0) || (op.five_diag && op.ndiag <= 2))))
+    return false;
+  const dim3 b(g.nc >= 512 ? 256 : 64, 1, 1);
+  const unsigned gx = (unsigned)((g.nc / 2 + b.x - 1) / b.x);
+  // row chunks as short as the partial-sum buffer allows (5 x 8192 doubles), not shorter than an application's
+  long rows = kApplyRows;
+  while ((long)gx * ((g.nr + rows - 1) / rows) > 8192) rows *= 2;
+  const dim3 grid(gx, (unsigned)((g.nr + rows - 1) / rows), 1);
+  const int nblocks = (int)(grid.x * grid.y);
+  if (op.five_point) hipLaunchKernelGGL(k_ritz_march<0>, grid, b, 0, s, g, op, x, w, (int)rows, partials, nblocks);
+  else if (op.ndiag == 1) hipLaunchKernelGGL(k_ritz_march<1>, grid, b, 0, s, g, op, x, w, (int)rows, partials, nblocks);
+  else hipLaunchKernelGGL(k_ritz_march<2>, grid, b, 0, s, g, op, x, w, (int)rows, partials, nblocks);
+  launch_final_sums(s, 5, nblocks, partials, out);
+  return true;
 }
 
 void launch_wjacobi(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, const double* shifts, double omega, int k) {

@@ -57,6 +57,10 @@ struct KGrid {
 // All take the number of vectors k (grid z) and a device pointer to the k shifts.
 
 void launch_apply(hipStream_t s, KGrid g, KOp op, KVec src, KVec dst, const double* shifts, int k);
+// <x,x>, <x,w>, <w,w>, <x,A w>, <w,A w> in one pass over x and w (nothing stored): true when the level's operator is
+// covered (2-D 5-point, with or without a product potential); out[0..4] on the device, partials: 5 * 8192 doubles
+bool launch_ritz_pair(hipStream_t s, KGrid g, KOp op, const double* x, const double* w, double* partials, double* out);
+void launch_final_sums(hipStream_t s, int nq, int nblocks, const double* partials, double* out);
 void launch_wjacobi(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, const double* shifts, double omega, int k);
 void launch_mc_colour(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const double* shifts, double omega, int ca, int cb, int k);
 void launch_residual(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, KVec r, const double* shifts, int k);

@@ -1089,6 +1089,41 @@ int mgcmt_gram(mgcmt_plan* p, int l, int nv, const int* slots, const int* vecs, 
   return MGCMT_OK;
 }
 
+int mgcmt_ritz_pair(mgcmt_plan* p, int l, int xs, int xv, int ws, int wv, int ss, int sv, double* out5, void* stream) {
+  MG_TRY(check_vec(p, l, xs, xv));
+  MG_TRY(check_vec(p, l, ws, wv));
+  MG_TRY(check_vec(p, l, ss, sv));
+  if (!out5) return fail(MGCMT_ERR_INVALID, "null output");
+  if ((ss == xs && sv == xv) || (ss == ws && sv == wv)) return fail(MGCMT_ERR_INVALID, "ritz_pair: the scratch vector must differ from x and w");
+  MG_TRY(ensure_slot(p, l, xs));
+  MG_TRY(ensure_slot(p, l, ws));
+  hipStream_t s = S(stream);
+  const double* x = p->kvec(l, xs, xv).p;
+  const double* w = p->kvec(l, ws, wv).p;
+  if (launch_ritz_pair(s, p->kgrid(l), p->levels[l].dA.k, x, w, p->d_partials, p->d_scalars)) {
+    MG_TRY(post_launch());
+    MG_HIP(hipMemcpyAsync(out5, p->d_scalars, sizeof(double) * 5, hipMemcpyDeviceToHost, s));
+    MG_HIP(hipStreamSynchronize(s));
+    return MGCMT_OK;
+  }
+  MG_TRY(ensure_slot(p, l, ss));
+  launch_apply(s, p->kgrid(l), p->levels[l].dA.k, p->kvec(l, ws, wv), p->kvec(l, ss, sv), p->d_zero, 1);
+  const double* v[kGramMaxVectors] = {x, w, p->kvec(l, ss, sv).p};
+  launch_gram(s, p->interior(l), v, 3, p->d_partials, p->d_scalars);
+  MG_TRY(post_launch());
+  constexpr int kPairs = kGramMaxVectors * (kGramMaxVectors + 1) / 2;
+  double packed[kPairs];
+  MG_HIP(hipMemcpyAsync(packed, p->d_scalars, sizeof(packed), hipMemcpyDeviceToHost, s));
+  MG_HIP(hipStreamSynchronize(s));
+  // packed order: (0,0),(0,1),...,(0,5),(1,1),(1,2),...
+  out5[0] = packed[0];
+  out5[1] = packed[1];
+  out5[2] = packed[kGramMaxVectors];
+  out5[3] = packed[2];
+  out5[4] = packed[kGramMaxVectors + 1];
+  return MGCMT_OK;
+}
+
 int mgcmt_rayleigh_residual(mgcmt_plan* p, int l, int slot, int k, double* rq_out, double* res_out, void* stream) {
   MG_TRY(check_vec(p, l, slot, 0));
   MG_TRY(check_k(p, k));

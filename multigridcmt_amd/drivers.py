@@ -215,9 +215,9 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
                      quotient over span{x, w} — the 2x2 problem of rqmin (MGCMTSolver.py:44-50) with the
                      preconditioned residual as the search direction.  All vector work stays in HBM: per iteration
                      one V-cycle from a zero start (a flag: V is neither cleared nor read), one operator application (a
-                     row march at streaming speed), ONE Gram-matrix pass over x, w, H w whose six numbers are all the host
-                     sees, and ONE combination pass that writes the new x and the new eigen-residual (the iteration carries
-                     the residual instead of H x: 22 instead of 26 vector passes' worth of traffic per iteration).
+                     row march that forms H w in registers and reduces the five inner products of the 2x2 problem without
+                     storing it), the update of x in place and ONE shifted application for the new eigen-residual
+                     (H - rho I) x: 7 vector passes' worth of traffic per iteration beside the cycle.
     Returns (rho, x); ``history`` (a list) receives rho after every cycle, ``stats`` (a dict) the seconds spent in
     the iteration loop alone (start vector generation and the host transfers excluded)."""
     from . import _lib
@@ -241,37 +241,33 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
         raise ValueError("method must be 'rqmg' or 'vcycle'")
     kind, omega = (_lib.GS_MC, 1.0) if smoother == "rb" else (_lib.WJACOBI, 2. / 3.)
     V, F, W = _lib.SLOT_V, _lib.SLOT_F, _lib.SLOT_W
-    X, AW, PW, R = (W, 0), (W, 1), (V, 0), (F, 0)
+    # x lives in column 1, so that its eigen-residual r = (H - rho I) x is ONE operator application with the shift of
+    # column 1 (= rho) while the V-cycle on column 0 keeps the unshifted Hamiltonian (shift 0)
+    X, PW, R, SCRATCH = (W, 1), (V, 0), (F, 0), (W, 0)
     plan = get_plan(op, int(lowest), nvec=2)
-    plan.set_shifts(np.zeros(2))
-    plan.upload(0, W, 0, x0)
+    plan.set_shifts([0.0, 0.0])
+    plan.upload(0, X[0], X[1], x0)
     plan.scale(0, 1.0 / np.sqrt(plan.dot(0, X, X)), X)
-    plan.apply(0, X, AW)
-    rho = plan.dot(0, X, AW)
-    plan.lincomb(0, [(1.0, AW), (-rho, X)], R)                                        # r = H x - rho x
+    plan.apply(0, X, SCRATCH)
+    rho = plan.dot(0, X, SCRATCH)
+    plan.set_shifts([0.0, rho])
+    plan.apply(0, X, R, with_shift=True)                                              # r = H x - rho x
     import time
     loop_start = time.perf_counter()
     for it in range(cycles):
-        # The iteration carries x and its eigen-residual r (the V-cycle's right-hand side), not H x: with
-        # x' = a x + b w the new residual is  r' = a r + a (rho - rho') x + b H w - rho' b w  — the same vectors the
-        # update of x reads — and <x, H x> = rho is known from the previous 2x2 problem.
         plan.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu, zero_start=True)        # w = B r  (V is not read: a flag)
-        plan.apply(0, PW, AW)
-        G = plan.gram(0, [X, PW, AW])                                                 # one pass over three vectors, one host round trip
-        xx, xw, ww, xaw, waw = G[0, 0], G[0, 1], G[1, 1], G[0, 2], G[1, 2]
+        # <x,x>, <x,w>, <w,w>, <x,H w>, <w,H w> in ONE pass over x and w (H w is formed in registers, never stored); <x,H x>
+        # is the Ritz value of the previous 2x2 problem
+        xx, xw, ww, xaw, waw = plan.ritz_pair(0, X, PW, SCRATCH)
         xax = rho * xx
         evals, evecs = scipy.linalg.eigh(np.array([[xax, xaw], [xaw, waw]]), np.array([[xx, xw], [xw, ww]]))
         a, b = evecs[:, 0]
         nrm = np.sqrt(a * a * xx + 2 * a * b * xw + b * b * ww)                       # |a x + b w|
-        a, b = a / nrm, b / nrm
-        new_rho = float(evals[0])                                                     # = <x', H x'> of x' = a x + b w
-        # x' and r' in ONE pass over the four vectors (every input read once; the last iteration needs no residual)
-        coeffs = [[a, a * (rho - new_rho)], [b, -new_rho * b], [0.0, b], [0.0, a]]
-        if it + 1 == cycles:
-            plan.block_combine(0, [X, PW, AW, R], [X], [row[:1] for row in coeffs])
-        else:
-            plan.block_combine(0, [X, PW, AW, R], [X, R], coeffs)
-        rho = new_rho
+        plan.lincomb(0, [(a / nrm, X), (b / nrm, PW)], X)                             # x <- (a x + b w) / |a x + b w|
+        rho = float(evals[0])                                                         # = <x, H x> of the new x
+        if it + 1 < cycles:
+            plan.set_shifts([0.0, rho])
+            plan.apply(0, X, R, with_shift=True)                                      # the new eigen-residual, exactly
         if history is not None:
             history.append(rho)
     if stats is not None:
@@ -279,10 +275,10 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
     if cycles > 0:
         # what is returned is MEASURED on the returned vector — <x, H x>/<x, x> — not the running value of the 2x2 problems
         # (which the history holds; the two agree to the accuracy fp64 gives this quotient: eps * |H| / rho, 1e-10 at 8192^2)
-        plan.apply(0, X, AW)
-        G = plan.gram(0, [X, AW])
+        plan.apply(0, X, SCRATCH)
+        G = plan.gram(0, [X, SCRATCH])
         rho = float(G[0, 1] / G[0, 0])
-    return rho, plan.download(0, W, 0)
+    return rho, plan.download(0, X[0], X[1])
 
 
 def block_eigensolve(op, k=4, cycles=12, nu=2, lowest=8, smoother="rb", seed=0, guesses=None, history=None, residuals=None,

@@ -164,6 +164,14 @@ class Plan:
         check(_lib.lib().mgcmt_gram(self._h, level, nv, slots, vecs, _lib.as_dp(out), stream))
         return out
 
+    def ritz_pair(self, level, x, w, scratch, stream=None):
+        """(<x,x>, <x,w>, <w,w>, <x,A w>, <w,A w>) with the unshifted operator of `level`: the 2 x 2 Rayleigh-Ritz problem
+        on span{x, w} when <x, A x> is known.  One pass over x and w on 2-D 5-point levels (nothing stored); `scratch`
+        ((slot, vec), distinct from x and w) receives A w elsewhere.  Synchronises."""
+        out = np.zeros(5)
+        check(_lib.lib().mgcmt_ritz_pair(self._h, level, x[0], x[1], w[0], w[1], scratch[0], scratch[1], as_dp(out), stream))
+        return out
+
     def rayleigh_residual(self, level, slot, k, stream=None):
         """(rq, res): Rayleigh quotients <v, A v>/<v, v> and residual norms ||(A - mu I) v|| of columns 0..k-1 of `slot`
         (mu = the plan's shifts); one synchronisation for all columns.  Slot W is the scratch."""

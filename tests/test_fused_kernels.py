@@ -308,6 +308,38 @@ def test_marching_apply_against_assembled_matrix(backend):
             p.close()
 
 
+def test_ritz_pair_against_assembled_matrix(backend):
+    """mgcmt_ritz_pair — <x,x>, <x,w>, <w,w>, <x,A w>, <w,A w> of rqmin's 2 x 2 pencil (MGCMTSolver.py:44-50) in one pass
+    over x and w on 5-point levels (Laplacian, square well), composed from an application and a Gram pass elsewhere (level 1:
+    9-point operators) — against the assembled matrices, vectors in different slots and columns, a grid with several row
+    chunks per column block and one narrower than a wave."""
+    from multigridcmt_amd.operators import potential_well_operator
+    from multigridcmt_amd.stencil_maker import MGCMTStencilMaker
+    SM = MGCMTStencilMaker()
+    rng = np.random.RandomState(31)
+    for g in (16, 128):
+        for make in (lambda g: laplacian_operator(g, "2d") * SCALE, lambda g: potential_well_operator(g, 33.0, (g // 4, 3 * g // 4))):
+            op = make(g)
+            p = Plan(op, 8, nvec=2)
+            p.set_shifts([0.7, -0.2])                         # the pencil uses the unshifted operator whatever the shifts
+            A = op.tocsr()
+            for level in (0, 1):
+                gl = g >> level
+                if level:
+                    A = (SM.restriction(2 * gl, gl, dimension="2d") @ A @ SM.interpolation(gl, 2 * gl, dimension="2d")).tocsr()
+                x, w = rng.rand(gl * gl) - 0.5, rng.rand(gl * gl) - 0.5
+                X, W, S = (_lib.SLOT_W, 1), (_lib.SLOT_V, 0), (_lib.SLOT_W, 0)
+                p.upload(level, X[0], X[1], x)
+                p.upload(level, W[0], W[1], w)
+                got = p.ritz_pair(level, X, W, S)
+                aw = A @ w
+                want = np.array([x @ x, x @ w, w @ w, x @ aw, w @ aw])
+                assert np.all(np.abs(got - want) <= 1e-12 * np.abs(want).max()), (g, level, got, want)
+            with pytest.raises(_lib.MgcmtError):
+                p.ritz_pair(0, X, W, W)
+            p.close()
+
+
 def test_marching_apply_on_galerkin_levels(backend):
     """mgcmt_apply on the coarser levels (k_apply_march_terms: any sum of Kronecker terms) — operator A and mass operator
     M, the six applications per step and level of the reference's Rayleigh-quotient multigrid (MGCMTSolver.py:17-57,
