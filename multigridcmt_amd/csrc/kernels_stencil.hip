@@ -75,7 +75,10 @@ __global__ void k_apply(KGrid g, KOp op, KVec src, KVec dst, const double* __res
 // per point at streaming speed.  The one-thread-per-point k_apply evaluates all Kronecker terms with their factor
 // loads at every point: 0.92 ms per 8192^2 square-well application against 0.2 ms of traffic — a fifth of a
 // Rayleigh-quotient iteration of BASELINE config 5.  Same arithmetic order as k_apply's five_point branch.
-constexpr int kApplyRows = 32;
+#ifndef MGCMT_APPLY_ROWS
+#define MGCMT_APPLY_ROWS 32
+#endif
+constexpr int kApplyRows = MGCMT_APPLY_ROWS;
 template <int ND>
 __global__ void __launch_bounds__(256) k_apply_march(KGrid g, KOp op, KVec src, KVec dst, const double* __restrict__ shifts) {
   const long j = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
