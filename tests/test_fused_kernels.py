@@ -17,7 +17,7 @@ def _run(g, fused, kind, omega, what, nu, shift=0.7, k=1, gs=False, seed=0, rows
     rng = np.random.RandomState(seed)
     p = Plan(op, 8, nvec=k)
     p.set_option(_lib.OPT_FUSED, fused)
-    p.set_option(_lib.OPT_FUSED_ROWS, rows)      # rows a wave marches over (0 = automatic); process-wide
+    p.set_option(_lib.OPT_FUSED_ROWS, rows)      # rows a wave marches over (0 = automatic); a setting of this plan
     p.set_option(_lib.OPT_RECOMPUTE, recompute)  # 2: recompute-instead-of-store on every fused level
     p.set_shifts(np.full(k, shift) + 0.1 * np.arange(k))
     for q in range(k):
@@ -201,7 +201,6 @@ def test_fused_constant_part_plus_product_term(backend, kind, omega, variable_la
             res.append(p.download(0, _lib.SLOT_V, 0))
             res.append(p.download(2, _lib.SLOT_F, 0))
         outs.append(res)
-        p.set_option(_lib.OPT_FUSED_ROWS, 0)
         p.close()
     for other in outs[:-1]:
         for a, b in zip(other, outs[-1]):
