@@ -77,6 +77,7 @@ struct FusedArgs {
   int rows_per_chunk;  // rows a wave marches over (even), plus the overlap
   int out_lo, out_hi;  // local rows this launch produces (even bounds; 0 .. nr for a whole pass)
   int rows_override;   // tuning: rows per chunk, 0 = automatic (host side only)
+  int xcd_balanced;    // workgroup -> tile mapping: 1 = equal shares of the tile list per XCD, 0 = whole column groups per XCD
 };
 
 #ifndef MGCMT_FUSED_NT_STORE
@@ -520,10 +521,25 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
 #else
   const int b = blockIdx.x;
   const int xcd = b & 7, seq = b >> 3;
-  const int per_xcd = (a.n_col_groups + 7) >> 3;
-  const int group = xcd * per_xcd + seq % per_xcd;
-  const int chunk = seq / per_xcd;
-  if (seq % per_xcd + xcd * per_xcd >= a.n_col_groups || chunk >= a.n_row_chunks) return;
+  int group, chunk;
+  if (a.xcd_balanced) {
+    // Every XCD gets the same number of (column group, row chunk) items (+-1): a contiguous range of the chunk-major
+    // list, i.e. whole rows of chunks plus a partial one at either end, so neighbours in a row still share its L2.
+    // With whole column groups per XCD the last XCDs run short on narrow levels (19 groups: 3,3,3,3,3,3,1,0) and the
+    // launch lasts as long as the fullest XCD: 2048^2 passes -19 % (Jacobi) / -39 % (four-colour), 4096^2 -11 %,
+    // 8192^2 -6 % with this mapping; at 16384^2 (147 groups: 3 % imbalance) the column bands are 6 % faster and stay.
+    const long total = (long)a.n_col_groups * a.n_row_chunks;
+    const long lo = xcd * total / 8, hi = (xcd + 1) * total / 8;
+    if (lo + seq >= hi) return;
+    const int item = (int)(lo + seq);
+    chunk = item / a.n_col_groups;
+    group = item - chunk * a.n_col_groups;
+  } else {
+    const int per_xcd = (a.n_col_groups + 7) >> 3;
+    group = xcd * per_xcd + seq % per_xcd;
+    chunk = seq / per_xcd;
+    if (seq % per_xcd + xcd * per_xcd >= a.n_col_groups || chunk >= a.n_row_chunks) return;
+  }
 #endif
   if (group >= a.n_col_groups) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1014,6 +1030,15 @@ void launch_one(hipStream_t s, FusedArgs a, int k) {
   rows = (rows + 1) & ~1L;
   a.rows_per_chunk = (int)rows;
   a.n_row_chunks = (int)((nrows + rows - 1) / rows);
+  // equal shares where whole column groups would leave the XCDs more than MGCMT_FUSED_XCD_IMBALANCE % apart — on levels up
+  // to 8192 columns; the 16384^2 level keeps its column bands (measured 6 % faster there)
+#ifndef MGCMT_FUSED_XCD_IMBALANCE
+#define MGCMT_FUSED_XCD_IMBALANCE 4
+#endif
+#ifndef MGCMT_FUSED_XCD_MAXGROUPS
+#define MGCMT_FUSED_XCD_MAXGROUPS 128
+#endif
+  a.xcd_balanced = (groups8 * 100 > groups * (100 + MGCMT_FUSED_XCD_IMBALANCE) && groups < MGCMT_FUSED_XCD_MAXGROUPS) ? 1 : 0;
   const unsigned blocks = (unsigned)(groups8 * a.n_row_chunks);
   hipLaunchKernelGGL((k_fused<OP, KIND, NSWEEP, FLAGS>), dim3(blocks, (unsigned)k), dim3(64 * kWavesPerBlock), 0, s, a);
 }
