@@ -527,7 +527,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
     // list, i.e. whole rows of chunks plus a partial one at either end, so neighbours in a row still share its L2.
     // With whole column groups per XCD the last XCDs run short on narrow levels (19 groups: 3,3,3,3,3,3,1,0) and the
     // launch lasts as long as the fullest XCD: 2048^2 passes -19 % (Jacobi) / -39 % (four-colour), 4096^2 -11 %,
-    // 8192^2 -6 % with this mapping; at 16384^2 (147 groups: 3 % imbalance) the column bands are 6 % faster and stay.
+    // 8192^2 -6 % with this mapping; at 16384^2 (147 groups: 3 % imbalance) the column bands are 6 % faster and stay —
+    // also against column bands with equal shares (the group at either end of a band split by rows between two XCDs,
+    // walked chunk by chunk: 16384^2 cycle 2.98 -> 3.07 ms).
     const long total = (long)a.n_col_groups * a.n_row_chunks;
     const long lo = xcd * total / 8, hi = (xcd + 1) * total / 8;
     if (lo + seq >= hi) return;

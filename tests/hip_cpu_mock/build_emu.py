@@ -12,6 +12,12 @@ OUT = os.path.join(OUT_DIR, "libmgcmt_emu.so")
 
 
 def build(force=False):
+    """MGCMT_EMU_EXTRA (tuning experiments): extra compiler flags; the library then goes to libmgcmt_emu_extra.so."""
+    extra = os.environ.get("MGCMT_EMU_EXTRA", "").split()
+    global OUT
+    if extra:
+        OUT = os.path.join(OUT_DIR, "libmgcmt_emu_extra.so")
+        force = True
     srcs = sorted(glob.glob(os.path.join(ROOT, "multigridcmt_amd", "csrc", "*.hip")))
     deps = srcs + glob.glob(os.path.join(ROOT, "multigridcmt_amd", "csrc", "*.h")) + \
         glob.glob(os.path.join(ROOT, "include", "*.h")) + \
@@ -22,11 +28,11 @@ def build(force=False):
     objs = []
     procs = []
     for src in srcs + [os.path.join(HERE, "hipmock_runtime.cpp")]:
-        obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
+        obj = os.path.join(OUT_DIR, os.path.basename(src) + (".extra.o" if extra else ".o"))
         objs.append(obj)
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "c++", "-I", HERE,
                "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "multigridcmt_amd", "csrc"),
-               "-c", src, "-o", obj]
+               "-c", src, "-o", obj] + extra
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()
