@@ -1020,7 +1020,10 @@ void launch_one(hipStream_t s, FusedArgs a, int k) {
   if (nrows <= 0) return;
   long rows = a.rows_override;
   if (rows <= 0) {
-    long chunks = (long)(0.9 * resident_blocks) / (groups * k);
+#ifndef MGCMT_FUSED_FILL
+#define MGCMT_FUSED_FILL 0.9  // re-measured after the mapping change: 0.8 / 0.9 / 1.0 -> 3.00-3.02 / 2.92-2.93 / 2.94-2.97 ms per 16384^2 cycle
+#endif
+    long chunks = (long)(MGCMT_FUSED_FILL * resident_blocks) / (groups * k);
     if (chunks < 1) chunks = 1;
     rows = (nrows + chunks - 1) / chunks;
     // (second session: with the dependency-cone skip a Jacobi chunk of 2 rows beats 4 on small levels — 256^2 cycle 0.057 ->
