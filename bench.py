@@ -50,13 +50,21 @@ def parse(argv=None):
     ap.add_argument("--switch-grid", type=int, default=None, help="multi-GPU: grid below which every rank runs the whole problem")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
                     help="multi-GPU halo exchange: RCCL inside libmgcmt_hip.so (default) or torch.distributed point-to-point")
+    ap.add_argument("--emulate-rank", type=int, default=None, metavar="R",
+                    help="with --gpus 1: this GPU does rank R's share of an --of N rank job on the multi-GPU grid (strip passes, "
+                         "RCCL exchanges with itself, gather, redundant coarse sub-cycle), timed like the N-rank leg")
+    ap.add_argument("--of", type=int, default=8, help="job size for --emulate-rank")
+    ap.add_argument("--no-verify", action="store_true", help="multi-GPU: skip rank 0's single-plan reference run")
     ap.add_argument("--config", type=int, choices=[1, 2, 3], default=None,
                     help="a BASELINE.json config by index: 1 = 4096^2 V(2,2) red-black, 2 = 16384^2 weighted Jacobi (the default, "
                          "the one `metric` is quoted on), 3 = 32768^2 V(2,2) red-black (the multi-GPU config; fits one GPU too)")
     args = ap.parse_args(argv)
     if args.config is not None:
         args.grid, args.smoother = {1: (4096, "rb"), 2: (16384, "wjacobi"), 3: (32768, "rb")}[args.config]
-    many = args.gpus > 1
+    many = args.gpus > 1 or args.emulate_rank is not None
+    args.emulate = None if args.emulate_rank is None else (args.emulate_rank, args.of)
+    if args.emulate is not None:
+        args.force_sharded = True
     if args.grid is None:
         args.grid = 32768 if many else 16384
     if args.smoother is None:
@@ -135,7 +143,7 @@ def traffic_record(args, smoother, nsweep):
     try:
         with open(path) as fh:
             table = json.load(fh)
-        key = "%s_%d" % (smoother, args.grid)
+        key = "%s_%d" % (smoother, args.grid)   # e.g. wjacobi_16384 (stand-alone pass), wjacobi_up_16384 (the cycle's up pass)
         val = table.get(key)
         if val is None:
             return None, None
@@ -178,6 +186,59 @@ def pass_roofline(plan, args, kind, smoother, omega, n, reps=25):
     return rec
 
 
+def cycle_compulsory_bytes(plan, nu, kind):
+    """Bytes one V(nu,nu) cycle HAS to move, level by level, with the plan's own traffic-saving modes:
+    a down pass reads V (not below the top level: the coarse iterate starts at zero) and F, writes V' (not on levels of
+    >= 2^22 points: recompute instead of store) and the coarse right-hand side (2 B per fine point); an up pass reads V
+    (unless it is still the untouched zero), F and the coarse correction and writes V'.  Only levels on the fused passes
+    count (the LDS-resident tail below moves a few KB)."""
+    total = 0.0
+    for l in range(plan.num_levels - 1):
+        r, c, _ = plan.shapes[l]
+        pts = float(r) * c
+        if plan.fused_max_sweeps(l, kind) == 0:
+            break
+        recompute = pts >= (1 << 22) and nu <= 2
+        top = l == 0
+        down = (8 if top else 0) + 8 + (0 if recompute else 8) + 2
+        up = (8 if (top or not recompute) else 0) + 8 + 2 + 8
+        total += pts * (down + up)
+    return total
+
+
+def cycle_roofline(plan, args, kind, smoother, omega, n, ms_per_step, reps=20):
+    """The roofline record of the timed region: the fine level's down pass (pre-smoothing + residual + restriction, V' not
+    stored: 18 B per point compulsory) and up pass (pre-smoothing recomputed + correction + post-smoothing: 26 B) timed
+    with HIP events on the stream they run on (mgcmt_time_fused_pass), the slower one as the record's kernel, and the
+    whole cycle's compulsory bytes over its measured time."""
+    from multigridcmt_amd import _lib
+    nu = args.nu
+    multicolour = kind != _lib.WJACOBI
+    passes = []
+    try:
+        npre = min(nu, plan.fused_max_recompute(0, kind, min(nu, 2)))
+        down_mode = 2 | (8 if npre == nu else 0)
+        up_mode = 1 | ((npre if npre == nu else 0) << 4)
+        kid = 1 if multicolour else 0
+        for name, mode, bpp, flags in (("down", down_mode, 18.0 if npre == nu else 26.0, down_mode & 15),
+                                       ("up", up_mode, 26.0, (up_mode & 15) | ((up_mode >> 4) << 4))):
+            ms = plan.time_fused_pass(0, kind, min(nu, 2), omega, mode, reps)
+            passes.append({"pass": name, "kernel": "k_fused<Op5,%d,%d,%d>" % (kid, min(nu, 2), flags), "avg_launch_ms": ms,
+                           "compulsory_bytes_per_launch": n * bpp, "achieved": n * bpp / (ms * 1e-3) / 1e9,
+                           "frac": n * bpp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        plan.fill(0, _lib.SLOT_V, 0, 0.0)               # (the timed passes left V arbitrary)
+    except Exception as e:                              # a plan whose fine level is not on the fused passes
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "error": str(e)}
+    dom = max(passes, key=lambda r: r["avg_launch_ms"])
+    traffic, source = traffic_record(args, smoother + "_" + dom["pass"], 0)
+    cyc = cycle_compulsory_bytes(plan, nu, kind)
+    return {"bound": "hbm", "kernel": "%s: the fine level's %s pass of the timed cycle" % (dom["kernel"], dom["pass"]),
+            "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+            "bytes_per_launch": dom["compulsory_bytes_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
+            "traffic": traffic, "traffic_source": source, "passes": passes,
+            "cycle_compulsory_bytes": cyc, "cycle_compulsory_frac": cyc / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def time_cycles(plan, steps, warmup, cycle):
     for _ in range(warmup):
         cycle()
@@ -210,8 +271,8 @@ def main(argv=None):
     op = laplacian_operator(g, "2d") * (-1.0 / np.pi ** 2)
     plan = Plan(op, args.lowest, nvec=1, device=0)
     plan.set_shifts([0.0])
-    rng = np.random.RandomState(1)
-    f = rng.rand(g * g)
+    from multigridcmt_amd import benchdata
+    f = benchdata.rhs(g)                       # block-seeded uniform(0,1) field: a multi-GPU rank can produce its own rows of it
     plan.upload(0, _lib.SLOT_F, 0, f)
     plan.fill(0, _lib.SLOT_V, 0, 0.0)
 
@@ -243,9 +304,11 @@ def main(argv=None):
         "vcycles_per_s": args.steps / elapsed,
         "device": _lib.device_name(0),
     }
-    # dominant kernel: the fused fine-level pass of the timed smoother
-    out["roofline"] = pass_roofline(plan, args, kind, args.smoother, omega, n)
-    out["smoother_mlups"] = out["roofline"]["smoother_mlups"]
+    # dominant kernels of the TIMED region: the fine level's two transfer-fused passes (the stand-alone smoother pass,
+    # which the cycle does not run, is `roofline_smoother`)
+    out["roofline"] = cycle_roofline(plan, args, kind, args.smoother, omega, n, out["ms_per_step"])
+    out["roofline_smoother"] = pass_roofline(plan, args, kind, args.smoother, omega, n)
+    out["smoother_mlups"] = out["roofline_smoother"]["smoother_mlups"]
     out["roofline"]["measured_ceilings_GBs"] = {
         name: n * bpp / (plan.bandwidth_probe(0, k_, 1024, 5) * 1e-3) / 1e9
         for k_, name, bpp in ((0, "copy", 16), (1, "triad", 24), (2, "read", 8))}
@@ -334,7 +397,31 @@ def main(argv=None):
             out["strong_scaling_base"] = {"workload": "2D Laplacian %d^2 fp64, V(%d,%d) red-black Gauss-Seidel, 1xMI355X (what --gpus N shards)" % (2 * g, args.nu, args.nu),
                                           "ms_per_step": t / steps * 1e3, "vcycles_per_s": steps / t,
                                           "value": 4 * n * sweeps * steps / t / 1e6, "unit": "MLUPS"}
+            # what `bench.py --gpus N` must reproduce (it prints the same two records for the same right-hand side)
+            from multigridcmt_amd.dist_bench import CHECK_CYCLES
+            Vb, Fb, Tb = (_lib.SLOT_V, 0), (_lib.SLOT_F, 0), (_lib.SLOT_T, 0)
+            big.fill(0, _lib.SLOT_V, 0, 0.0)
+            fb_norm = np.sqrt(big.dot(0, Fb, Fb))
+            hist = []
+            for _ in range(CHECK_CYCLES):
+                big.vcycle(args.nu, args.nu, _lib.GS_MC, omega=1.0, k=1, nu_coarse=args.nu)
+                big.apply(0, Vb, Tb, with_shift=True)
+                big.axpy(0, -1.0, Fb, Tb)
+                hist.append(float(np.sqrt(big.dot(0, Tb, Tb)) / fb_norm))
+            big.fill(0, _lib.SLOT_T, 0, 1.0)
+            out["strong_scaling_base"]["residual_reduction_per_cycle"] = hist
+            out["strong_scaling_base"]["checksum_after_%d_cycles" % CHECK_CYCLES] = [big.dot(0, Vb, Tb), big.dot(0, Vb, Vb)]
             big.close()
+            # ONE rank's share of the 8-rank job, on this GPU (an edge and an interior rank): strip passes, RCCL exchanges
+            # with itself, gather, redundant coarse sub-cycle — everything but the bytes' time on the xGMI links
+            try:
+                from multigridcmt_amd.dist_bench import time_rank_share
+                shares = [time_rank_share(2 * g, args.nu, args.lowest, "rb", r, 8) for r in (0, 3)]
+                out["strong_scaling_base"]["rank_share_of_8"] = shares
+                out["strong_scaling_base"]["ms_per_rank_share"] = max(x["ms_per_rank_share"] for x in shares)
+                out["strong_scaling_base"]["speedup_bound_from_rank_share"] = out["strong_scaling_base"]["ms_per_step"] / out["strong_scaling_base"]["ms_per_rank_share"]
+            except Exception as e:                              # RCCL not loadable on this box
+                out["strong_scaling_base"]["rank_share_of_8"] = {"value": None, "error": str(e)}
         except Exception as e:                                  # e.g. a smaller-memory device
             out["strong_scaling_base"] = {"value": None, "error": str(e)}
     if not args.no_extras and g == 16384:

@@ -33,9 +33,10 @@
 extern "C" {
 #endif
 
-#define MGCMT_ABI_VERSION 4
+#define MGCMT_ABI_VERSION 5
 #define MGCMT_MAX_TERMS 4
-#define MGCMT_HALO_ROWS 8 /* rows of halo kept above and below every level's vectors */
+#define MGCMT_HALO_ROWS 16 /* rows of halo kept above and below every vector of a 2-D level (a 1-D level keeps one: its
+                              "row" is the whole vector); how many of them a sharded cycle fills: mgcmt_plan_level_halo */
 
 typedef enum mgcmt_status {
   MGCMT_OK = 0,
@@ -92,9 +93,14 @@ int mgcmt_plan_num_levels(const mgcmt_plan* plan, int* levels);
 int mgcmt_plan_level_shape(const mgcmt_plan* plan, int level, int64_t* rows, int64_t* cols, int64_t* row_begin);
 /* host copy of a level's factors, [nterms][3][n] with n = global rows (which=0) or cols (which=1) */
 int mgcmt_plan_get_factors(const mgcmt_plan* plan, int op, int level, int which, double* out, int64_t capacity);
-/* device address of the interior (row 0, col 0) of vector `vec` in `slot` of `level`; rows
- * -MGCMT_HALO_ROWS..-1 and rows..rows+MGCMT_HALO_ROWS-1 are addressable halo rows */
+/* device address of the interior (row 0, col 0) of vector `vec` in `slot` of `level`; rows -halo..-1 and
+ * rows..rows+halo-1 are addressable halo rows (halo: mgcmt_plan_level_halo) */
 int mgcmt_vec_ptr(const mgcmt_plan* plan, int level, int slot, int vec, void** device_ptr);
+/* halo_rows: rows kept above and below every vector of `level` (MGCMT_HALO_ROWS on 2-D levels, 1 on 1-D levels);
+ * exchanged_rows: how many of them — the ones next to the strip — a sharded cycle fills with the neighbours' rows and its
+ * passes read: 8 on levels with a 5-point operator, 10 on the 9-point (Galerkin) levels, whose two four-colour sweeps plus
+ * restriction reach nine rows beyond a strip.  Either output may be NULL. */
+int mgcmt_plan_level_halo(const mgcmt_plan* plan, int level, int* halo_rows, int* exchanged_rows);
 
 /* shift(s) mu of (A - mu I): vcycle's shift= (MGCMTSolver.py:287-288), vcycle_matrix's shifts= (:385-388) */
 int mgcmt_set_shifts(mgcmt_plan* plan, const double* shifts, int k, void* stream);
@@ -190,7 +196,7 @@ int mgcmt_normalize(mgcmt_plan* plan, int level, int slot, int k, void* stream);
  * to be zero (it is then neither read nor required to have been cleared, :316); adding 8 to mode 2 suppresses the
  * store of the smoothed V ("recompute instead of store": a later mode-1 pass with (npre << 4) added re-runs those
  * npre sweeps from the untouched V before it adds the correction — also with 4 when that V is the zero iterate).
- * The pass reads MGCMT_HALO_ROWS halo rows of V
+ * The pass reads the exchanged halo rows (mgcmt_plan_level_halo) of V
  * and F (and of V[level+1] in mode 1) around a strip.  mgcmt_fused_max_sweeps: sweeps one pass can take on that
  * level (0 = the level is not covered by the fused kernels). */
 int mgcmt_fused_pass(mgcmt_plan* plan, int level, int kind, int nsweep, double omega, int mode, int k, void* stream);
@@ -237,26 +243,36 @@ typedef enum mgcmt_comm_option {
                                  the launch that produces the interior rows */
   MGCMT_COMM_OPT_SPLIT = 1,   /* default 1: boundary rows are produced by their own launches first on strips of >= 2^22 points (where the
                                  exchange they take off the critical path outweighs two more launches); 2: on every strip; 0: never */
-  MGCMT_COMM_OPT_SELF_RING = 2 /* default 0; 1 on a ONE-rank communicator: the rank acts as its own upper and lower neighbour in
-                                 every exchange of a cycle (the rows it receives are never read): the split launches, the
-                                 transport and the stream overlap run for real on one GPU */
+  MGCMT_COMM_OPT_SELF_RING = 2, /* default 0; 1 on a ONE-rank communicator: the rank acts as its own upper and lower neighbour in
+                                 every exchange of a cycle: the split launches, the transport and the stream overlap run
+                                 for real on one GPU (on a whole-grid plan the rows it receives are never read) */
+  MGCMT_COMM_OPT_EMULATE_OF = 3 /* default 0; N > 1 on a ONE-rank communicator in self-ring mode whose plan is the strip of
+                                 some rank R of an N-rank job: the cycle then does that rank's work — strip passes, the
+                                 exchanges (with itself), a gather of N strips' worth of data, the redundant coarse
+                                 sub-cycle — so that one GPU can time one rank's share (bench.py --emulate-rank).  The halo
+                                 rows hold the rank's own rows, so the numbers are not the N-rank job's */
 } mgcmt_comm_option;
 int mgcmt_comm_set_option(mgcmt_plan* plan, int option, int value);
-/* halo rows of vector 0 of the slots in slot_mask (bit s = slot s) on strip level `level` <- the chain neighbours'
- * boundary rows, one batch.  Adding 0x100 on a ONE-rank communicator treats the strip as a ring (it is its own upper
- * and lower neighbour): a self-test of the transport. */
+/* halo rows (the exchanged ones, mgcmt_plan_level_halo) of the slots in slot_mask (bit s = slot s) on strip level `level` <-
+ * the chain neighbours' boundary rows, one batch; vectors 0..k-1 with k in bits 16-23 of slot_mask (0 = vector 0 only).
+ * Adding 0x100 on a ONE-rank communicator treats the strip as a ring (it is its own upper and lower neighbour): a
+ * self-test of the transport. */
 int mgcmt_halo_exchange(mgcmt_plan* plan, int level, int slot_mask, void* stream);
-/* strips of (level, slot) of all ranks -> the whole-grid finest level of `coarse` (dst_slot) on every rank */
-int mgcmt_gather_coarse(mgcmt_plan* plan, int level, int slot, mgcmt_plan* coarse, int dst_slot, void* stream);
+/* strips of vectors 0..k-1 of (level, slot) of all ranks -> the whole-grid finest level of `coarse` (dst_slot) on every rank */
+int mgcmt_gather_coarse(mgcmt_plan* plan, int level, int slot, mgcmt_plan* coarse, int dst_slot, int k, void* stream);
 /* host_inout[0..n) <- sum over ranks (norms, inner products: the np.dot / np.linalg.norm call sites); synchronises */
 int mgcmt_allreduce_sum(mgcmt_plan* plan, double* host_inout, int n, void* stream);
-/* one V(nu1,nu2) cycle (MGCMTSolver.py:281-329) of the sharded hierarchy: `plan` holds the finest levels as row strips,
- * `coarse` the first whole-grid level and everything below it on every rank.  flags: the caller vouches that the halo
- * rows of the fine level's V (nothing but mgcmt_sharded_vcycle wrote V since the previous cycle) / F (since the
- * previous cycle with the same right-hand side) are still the neighbours' rows, which saves their exchange. */
+/* one V(nu1,nu2) cycle (MGCMTSolver.py:281-329) of the sharded hierarchy on vectors 0..k-1 (each with its own shift):
+ * `plan` holds the finest levels as row strips, `coarse` the first whole-grid level and everything below it on every
+ * rank.  flags: the caller vouches that the halo rows of the fine level's V (nothing but mgcmt_sharded_vcycle wrote V since
+ * the previous cycle) / F (since the previous cycle with the same right-hand side) are still the neighbours' rows, which
+ * saves their exchange; MGCMT_SHARDED_GRAM_SCHMIDT: vcycle_matrix (:375-436) — modified Gram-Schmidt of the k columns on
+ * every non-coarsest level on the way up (:434), on strip levels with ONE all-reduce of the column's coefficients per
+ * column (SURVEY par. 8e). */
 #define MGCMT_SHARDED_V_HALO_VALID 1
 #define MGCMT_SHARDED_F_HALO_VALID 2
-int mgcmt_sharded_vcycle(mgcmt_plan* plan, mgcmt_plan* coarse, int nu1, int nu2, int nu_coarse, int kind, double omega,
+#define MGCMT_SHARDED_GRAM_SCHMIDT 4
+int mgcmt_sharded_vcycle(mgcmt_plan* plan, mgcmt_plan* coarse, int nu1, int nu2, int nu_coarse, int kind, double omega, int k,
                          int flags, void* stream);
 
 /* ---- general sparse, complex128 operators -------------------------------------------------------
@@ -306,6 +322,12 @@ int mgcmt_plan_set_option(mgcmt_plan* plan, int option, int value);
  * HIP events on `stream` and returns the elapsed milliseconds */
 int mgcmt_time_smoother(mgcmt_plan* plan, int level, int kind, int nu, double omega, int reps, double* ms_out,
                         void* stream);
+
+/* the same for ONE fused pass of the cycle's timed region (mode as mgcmt_fused_pass: e.g. 2|8 = the fine level's
+ * restrict-without-store down pass, 1|(npre<<4) = its recompute + correct + post-smooth up pass): average milliseconds
+ * of `reps` launches between two HIP events on `stream` (one untimed launch first) */
+int mgcmt_time_fused_pass(mgcmt_plan* plan, int level, int kind, int nsweep, double omega, int mode, int reps, double* ms_out,
+                          void* stream);
 
 /* diagnostics of the last lexicographic wave-pipeline sweep (kernels_lexwave.hip): out[0] = blocks started, out[1] = error
  * word (a block timed out), and — only in a build with -DMGCMT_LEXWAVE_DEBUG — per block four words {ticks of the 100 MHz

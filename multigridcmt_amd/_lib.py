@@ -7,6 +7,7 @@ the SAME kernel sources, tests/hip_cpu_mock; nothing in this package calls it.)
 """
 import ctypes
 import os
+import sys
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -15,10 +16,10 @@ DEFAULT_LIBRARY = os.path.join(_HERE, "libmgcmt_hip.so")
 WJACOBI, GS_LEX, SOR_LEX, GS_MC = 0, 1, 2, 3
 SLOT_V, SLOT_F, SLOT_T, SLOT_W = 0, 1, 2, 3
 OP_A, OP_M = 0, 1
-HALO_ROWS = 8
+HALO_ROWS = 16         # 2-D levels (a 1-D level keeps one halo "row"); exchanged rows per level: Plan.level_halo
 MAX_TERMS = 4
 MAX_VEC = 32
-ABI_VERSION = 4
+ABI_VERSION = 5
 OPT_FUSED = 0
 OPT_FUSED_ROWS = 1
 OPT_TAIL = 4
@@ -53,8 +54,8 @@ P2P_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, POINTER(P2POp))
 ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_int64)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, _dp, c_int)
 UNIQUE_ID_BYTES = 128
-COMM_OPT_OVERLAP, COMM_OPT_SPLIT, COMM_OPT_SELF_RING = 0, 1, 2
-SHARDED_V_HALO_VALID, SHARDED_F_HALO_VALID = 1, 2
+COMM_OPT_OVERLAP, COMM_OPT_SPLIT, COMM_OPT_SELF_RING, COMM_OPT_EMULATE_OF = 0, 1, 2, 3
+SHARDED_V_HALO_VALID, SHARDED_F_HALO_VALID, SHARDED_GRAM_SCHMIDT = 1, 2, 4
 CYCLE_GRAM_SCHMIDT, CYCLE_ZERO_START = 1, 2    # cycle_flags of mgcmt_vcycle
 OPK_GENERAL, OPK_FIVE_POINT, OPK_FIVE_DIAG, OPK_NINE_CONST, OPK_NINE_VAR = 0, 1, 2, 3, 4    # mgcmt_level_operator_kind
 HALO_RING = 0x100
@@ -70,6 +71,7 @@ _SIGNATURES = {
     "mgcmt_plan_level_shape": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "mgcmt_plan_get_factors": (c_int, [c_void_p, c_int, c_int, c_int, _dp, c_int64]),
     "mgcmt_vec_ptr": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "mgcmt_plan_level_halo": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]),
     "mgcmt_set_shifts": (c_int, [c_void_p, _dp, c_int, c_void_p]),
     "mgcmt_upload": (c_int, [c_void_p, c_int, c_int, c_int, _dp, c_int64, c_void_p]),
     "mgcmt_download": (c_int, [c_void_p, c_int, c_int, c_int, _dp, c_int64, c_void_p]),
@@ -111,9 +113,9 @@ _SIGNATURES = {
     "mgcmt_comm_destroy": (c_int, [c_void_p]),
     "mgcmt_comm_set_option": (c_int, [c_void_p, c_int, c_int]),
     "mgcmt_halo_exchange": (c_int, [c_void_p, c_int, c_int, c_void_p]),
-    "mgcmt_gather_coarse": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mgcmt_gather_coarse": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "mgcmt_allreduce_sum": (c_int, [c_void_p, _dp, c_int, c_void_p]),
-    "mgcmt_sharded_vcycle": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p]),
+    "mgcmt_sharded_vcycle": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p]),
     "mgcmt_csr_plan_create": (c_int, [c_int, c_int64, c_int64, POINTER(c_int64), POINTER(c_int32), _dp, POINTER(c_void_p)]),
     "mgcmt_csr_plan_destroy": (c_int, [c_void_p]),
     "mgcmt_csr_num_levels": (c_int, [c_void_p, POINTER(c_int)]),
@@ -128,15 +130,50 @@ _SIGNATURES = {
     "mgcmt_bandwidth_probe": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _dp, c_void_p]),
     "mgcmt_lex_wave_stats": (c_int, [c_void_p, POINTER(ctypes.c_uint32), c_int64]),
     "mgcmt_time_smoother": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, _dp, c_void_p]),
+    "mgcmt_time_fused_pass": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_int, _dp, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 
 _lib = None
 _lib_path = None
+_torch_first = None        # was torch already imported when the library was bound?
+_torch_checked = False
+
+
+def _check_torch_order():
+    """Each of libmgcmt_hip.so and PyTorch brings a HIP runtime and only the first one loaded can open the device: a
+    process that imports torch AFTER its first call into this library is left with a torch that sees no GPU
+    ("Ownership") — silently.  Detected here on the first library use after such an import and raised
+    once, with the remedy; MGCMT_ALLOW_TORCH_AFTER=1 silences it (a process that only wants CPU tensors)."""
+    global _torch_checked
+    if _torch_checked or _torch_first is not False or "torch" not in sys.modules:
+        return
+    if _lib_path != DEFAULT_LIBRARY:       # (a test binding — the host-only emulation build has no HIP runtime to conflict with)
+        return
+    _torch_checked = True
+    if os.environ.get("MGCMT_ALLOW_TORCH_AFTER", "0") == "1":
+        return
+    torch = sys.modules["torch"]
+    try:
+        torch_sees_gpu = bool(torch.cuda.is_available())
+        n = c_int(0)
+        ours = _lib.mgcmt_device_count(ctypes.byref(n)) == 0 and n.value >= 1
+    except Exception:
+        return
+    if ours and not torch_sees_gpu:
+        raise MgcmtError(
+            "torch was imported after the first call into libmgcmt_hip.so and now sees no GPU (torch.cuda.is_available() is "
+            "False while this library sees %d device(s)): each brings a HIP runtime and only the first one loaded can open "
+            "the device.  Import torch BEFORE the first use of multigridcmt_amd in this process, or set "
+            "MGCMT_ALLOW_TORCH_AFTER=1 if torch is only used on the CPU." % n.value)
 
 
 def _bind(path):
+    global _torch_first, _torch_checked
+    if _torch_first is None:
+        _torch_first = "torch" in sys.modules
+        _torch_checked = _torch_first
     lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
@@ -169,6 +206,8 @@ def lib():
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % DEFAULT_LIBRARY)
         _lib = _bind(DEFAULT_LIBRARY)
         _lib_path = DEFAULT_LIBRARY
+    if not _torch_checked:
+        _check_torch_order()
     return _lib
 
 

@@ -444,7 +444,15 @@ int mgcmt_csr_plan_create(int device, int64_t n, int64_t lowest, const int64_t* 
     mgcmt_csr_plan_destroy(p);
     return rc;
   };
-  // level 0: the caller's matrix (rows sorted by column, as the chunk analysis and the kernels assume)
+  // level 0: the caller's matrix (rows sorted by column, as the chunk analysis and the kernels assume).  The row
+  // pointer is checked before anything is sized by it: a caller of the C-ABI need not be scipy.
+  if (indptr[0] != 0) return bail(fail(MGCMT_ERR_INVALID, "indptr[0] must be 0"));
+  for (int64_t k = 0; k < n; ++k)
+    if (indptr[k + 1] < indptr[k]) return bail(fail(MGCMT_ERR_INVALID, "indptr must be non-decreasing"));
+  auto copied = [&](hipError_t e, const char* what) -> int {  // a failed copy must not leave a silently wrong hierarchy
+    if (e == hipSuccess) return MGCMT_OK;
+    return fail(MGCMT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  };
   std::vector<long> ptr(indptr, indptr + n + 1);
   std::vector<int> idx(indices, indices + ptr[n]);
   std::vector<cplx> val((size_t)ptr[n]);
@@ -473,9 +481,10 @@ int mgcmt_csr_plan_create(int device, int64_t n, int64_t lowest, const int64_t* 
       if (hipMalloc((void**)&L.indptr, sizeof(long) * (L.n + 1)) != hipSuccess || hipMalloc((void**)&L.indices, sizeof(int) * std::max<long>(L.nnz, 1)) != hipSuccess ||
           hipMalloc((void**)&L.vals, sizeof(cplx) * std::max<long>(L.nnz, 1)) != hipSuccess)
         return bail(fail(MGCMT_ERR_NOMEM, "csr level"));
-      (void)hipMemcpy(L.indptr, ptr.data(), sizeof(long) * (L.n + 1), hipMemcpyHostToDevice);
-      (void)hipMemcpy(L.indices, idx.data(), sizeof(int) * L.nnz, hipMemcpyHostToDevice);
-      (void)hipMemcpy(L.vals, val.data(), sizeof(cplx) * L.nnz, hipMemcpyHostToDevice);
+      int rc = copied(hipMemcpy(L.indptr, ptr.data(), sizeof(long) * (L.n + 1), hipMemcpyHostToDevice), "csr level 0: indptr");
+      if (rc == MGCMT_OK) rc = copied(hipMemcpy(L.indices, idx.data(), sizeof(int) * L.nnz, hipMemcpyHostToDevice), "csr level 0: indices");
+      if (rc == MGCMT_OK) rc = copied(hipMemcpy(L.vals, val.data(), sizeof(cplx) * L.nnz, hipMemcpyHostToDevice), "csr level 0: values");
+      if (rc != MGCMT_OK) return bail(rc);
     } else {
       // Galerkin product of the finer level, on the device: count, prefix sum, fill
       const CsrLevel& F = p->levels[l - 1];
@@ -483,14 +492,21 @@ int mgcmt_csr_plan_create(int device, int64_t n, int64_t lowest, const int64_t* 
       int* d_over = nullptr;
       if (hipMalloc((void**)&d_counts, sizeof(long) * L.n) != hipSuccess || hipMalloc((void**)&d_over, sizeof(int)) != hipSuccess)
         return bail(fail(MGCMT_ERR_NOMEM, "csr level"));
-      (void)hipMemset(d_over, 0, sizeof(int));
-      hipLaunchKernelGGL(k_csr_rap<false>, dim3(blocks_for(L.n, 64)), dim3(64), 0, nullptr, kcsr(F), L.n, d_counts, (const long*)nullptr, (int*)nullptr,
-                         (cplx*)nullptr, d_over);
+      int rc = copied(hipMemset(d_over, 0, sizeof(int)), "Galerkin product: overflow flag");
       std::vector<long> counts(L.n);
       int over = 0;
-      (void)hipMemcpy(counts.data(), d_counts, sizeof(long) * L.n, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(&over, d_over, sizeof(int), hipMemcpyDeviceToHost);
+      if (rc == MGCMT_OK) {
+        hipLaunchKernelGGL(k_csr_rap<false>, dim3(blocks_for(L.n, 64)), dim3(64), 0, nullptr, kcsr(F), L.n, d_counts, (const long*)nullptr, (int*)nullptr,
+                           (cplx*)nullptr, d_over);
+        rc = copied(hipGetLastError(), "Galerkin product: count launch");
+      }
+      if (rc == MGCMT_OK) rc = copied(hipMemcpy(counts.data(), d_counts, sizeof(long) * L.n, hipMemcpyDeviceToHost), "Galerkin product: counts");
+      if (rc == MGCMT_OK) rc = copied(hipMemcpy(&over, d_over, sizeof(int), hipMemcpyDeviceToHost), "Galerkin product: overflow flag");
       (void)hipFree(d_counts);
+      if (rc != MGCMT_OK) {
+        (void)hipFree(d_over);
+        return bail(rc);
+      }
       if (over) {
         (void)hipFree(d_over);
         return bail(fail(MGCMT_ERR_UNSUPPORTED, "a Galerkin row has more than 96 entries"));
@@ -503,14 +519,19 @@ int mgcmt_csr_plan_create(int device, int64_t n, int64_t lowest, const int64_t* 
         (void)hipFree(d_over);
         return bail(fail(MGCMT_ERR_NOMEM, "csr level"));
       }
-      (void)hipMemcpy(L.indptr, cptr.data(), sizeof(long) * (L.n + 1), hipMemcpyHostToDevice);
+      rc = copied(hipMemcpy(L.indptr, cptr.data(), sizeof(long) * (L.n + 1), hipMemcpyHostToDevice), "Galerkin product: indptr");
+      if (rc != MGCMT_OK) {
+        (void)hipFree(d_over);
+        return bail(rc);
+      }
       hipLaunchKernelGGL(k_csr_rap<true>, dim3(blocks_for(L.n, 64)), dim3(64), 0, nullptr, kcsr(F), L.n, (long*)nullptr, (const long*)L.indptr, L.indices,
                          L.vals, d_over);
       (void)hipFree(d_over);
       if (hipDeviceSynchronize() != hipSuccess) return bail(fail(MGCMT_ERR_HIP, "Galerkin product kernel failed"));
       ptr = cptr;
       idx.resize(L.nnz);
-      (void)hipMemcpy(idx.data(), L.indices, sizeof(int) * L.nnz, hipMemcpyDeviceToHost);
+      rc = copied(hipMemcpy(idx.data(), L.indices, sizeof(int) * L.nnz, hipMemcpyDeviceToHost), "Galerkin product: indices");
+      if (rc != MGCMT_OK) return bail(rc);
     }
     L.chunk = lex_chunk(L.n, ptr, idx);
     const int rc = alloc_vectors(L);

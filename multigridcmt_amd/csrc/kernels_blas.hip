@@ -596,11 +596,12 @@ void launch_mgs_small(hipStream_t s, long n, double* a0, long stride, int k) {
   hipLaunchKernelGGL(k_mgs_small, dim3(1), dim3(kMgsSmallThreads), 0, s, n, a0, stride, k);
 }
 
-void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out) {
+void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out, int nb_in) {
   const int nb = reduce_blocks(n);
+  if (nb_in <= 0) nb_in = nb;
   const bool vec2 = (n & 1) == 0 && (stride & 1) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0;
-  if (vec2) hipLaunchKernelGGL(k_mgs_step<true>, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb, u, stride, m, partials_out);
-  else hipLaunchKernelGGL(k_mgs_step<false>, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb, u, stride, m, partials_out);
+  if (vec2) hipLaunchKernelGGL(k_mgs_step<true>, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb_in, u, stride, m, partials_out);
+  else hipLaunchKernelGGL(k_mgs_step<false>, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb_in, u, stride, m, partials_out);
 }
 
 void launch_dots(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, double* out) {

@@ -17,12 +17,17 @@ bool fused_supported(const KGrid& g, const KOp& op) {
 }
 
 // sweeps one pass can fuse.  A 9-point four-colour sweep is four stages: two of them plus the restriction read nine
-// rows above the chunk, one more than a strip's MGCMT_HALO_ROWS, so strips (sharded levels) fuse one.
-int fused_max_sweeps(const KOp& op, int multicolour, bool strip) { return (!op.five_point && !op.five_diag && multicolour && strip) ? 1 : 2; }
+// rows above the chunk — strips (sharded levels) therefore exchange ten halo rows on 9-point levels (exchanged_rows,
+// plan.hip) and fuse two sweeps like the single plan (they fused one while a strip had eight halo rows).
+int fused_max_sweeps(const KOp& op, int multicolour) {
+  (void)op;
+  (void)multicolour;
+  return 2;
+}
 
 // sweeps of pre-smoothing an up-leg pass with `nsweep` post-smoothing sweeps can recompute in front of the
 // correction (0: none): all stages plus the correction must fit the window overlap (16 columns at most) and
-// the eight halo rows of a strip
+// the exchanged halo rows of a strip
 int fused_max_recompute(const KOp& op, int multicolour, int nsweep) {
   if (!op.five_point && !op.five_diag && multicolour) return 0;  // four-colour sweeps: four stages each
   const int per_sweep = multicolour ? 2 : 1;

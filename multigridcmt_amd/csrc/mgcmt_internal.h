@@ -15,7 +15,7 @@ constexpr int kMaxVec = 32;  // upper bound on simultaneous vectors of one launc
 
 // Operator of one level as the kernels see it:  A = sum_m X_m (x) Y_m  (shift applied separately).
 // X[m] / Y[m] point at element 0 of the `lower` array; `diag` is at +ldx, `upper` at +2*ldx.
-// Row factors are stored with kHalo entries before element 0 and after element nr-1 (the local
+// Row factors are stored with the level's halo count of entries before element 0 and after element nr-1 (the local
 // strip's halo rows; zero outside the global grid), column factors span the whole row.
 struct KOp {
   int nterms;
@@ -91,7 +91,7 @@ void launch_lex_band(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
 // residual+restrict last (coarse = right-hand side); mode & 4: vin is zero; mode & 8: vout is not written (mode 2);
 // npre: pre-smoothing sweeps recomputed in front of the correction (mode 1)
 bool fused_supported(const KGrid& g, const KOp& op);
-int fused_max_sweeps(const KOp& op, int multicolour, bool strip);
+int fused_max_sweeps(const KOp& op, int multicolour);
 int fused_max_recompute(const KOp& op, int multicolour, int nsweep);
 // rows_override: rows per wave chunk (0 = automatic); [out_lo, out_hi): the local rows this launch produces (even
 // bounds; the whole strip is 0 .. g.nr) — a sharded pass runs its boundary rows first so that their exchange overlaps
@@ -149,7 +149,8 @@ struct TailArgs {
 bool tail_fits(long g0, int nlev, int nterms);
 void launch_tail(hipStream_t s, const TailArgs& a, int k);
 void launch_mgs_small(hipStream_t s, long n, double* a0, long stride, int k);
-void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out);
+// nb_in: partial sums per result in partials_in (0 = reduce_blocks(n), what the previous step left; 1 = already summed)
+void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out, int nb_in = 0);
 
 // banded LU of (A - mu I) on the coarsest level and its solves (one workgroup per vector)
 struct KBand {

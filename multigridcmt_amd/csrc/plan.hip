@@ -68,14 +68,14 @@ int upload_op(const HostOp& h, const Level& L, int dim, DevOp* d) {
   KOp& k = d->k;
   k = KOp{};
   k.nterms = h.nterms;
-  k.ldx = L.nr + 2 * kHalo;
+  k.ldx = L.nr + 2 * L.halo;
   k.ldy = L.gc;
   for (int m = 0; m < h.nterms; ++m) {
     std::vector<double> xs(3 * k.ldx, 0.0);
     for (int part = 0; part < 3; ++part)
-      for (int64_t i = -kHalo; i < L.nr + kHalo; ++i) {
+      for (int64_t i = -L.halo; i < L.nr + L.halo; ++i) {
         const int64_t gi = L.r0 + i;
-        if (gi >= 0 && gi < L.gr) xs[part * k.ldx + (i + kHalo)] = h.X[m].a[part * L.gr + gi];
+        if (gi >= 0 && gi < L.gr) xs[part * k.ldx + (i + L.halo)] = h.X[m].a[part * L.gr + gi];
       }
     double *dx = nullptr, *dy = nullptr;
     MG_HIP(hipMalloc((void**)&dx, xs.size() * sizeof(double)));
@@ -84,7 +84,7 @@ int upload_op(const HostOp& h, const Level& L, int dim, DevOp* d) {
     MG_HIP(hipMalloc((void**)&dy, 3 * L.gc * sizeof(double)));
     d->owned.push_back(dy);
     MG_HIP(hipMemcpy(dy, h.Y[m].a.data(), 3 * L.gc * sizeof(double), hipMemcpyHostToDevice));
-    k.X[m] = dx + kHalo;
+    k.X[m] = dx + L.halo;
     k.Y[m] = dy;
   }
   // constant-coefficient 5-point (2-D) / 3-point (1-D) detection: every factor Toeplitz and the
@@ -267,8 +267,10 @@ int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mod
     coarse = p->kvec(l + 1, (mode & 3) == 1 ? MGCMT_SLOT_V : MGCMT_SLOT_F);
     cnc = p->levels[l + 1].gc;
   }
-  const long row_lo = L.r0 == 0 ? 0 : -kHalo;
-  const long row_hi = L.r0 + L.nr == L.gr ? L.nr : L.nr + kHalo;
+  // rows beyond a strip that hold the neighbours' data (the passes read no further: exchanged_rows)
+  const long hx = exchanged_rows(p, l);
+  const long row_lo = L.r0 == 0 ? 0 : -hx;
+  const long row_hi = L.r0 + L.nr == L.gr ? L.nr : L.nr + hx;
   launch_fused(s, p->kgrid(l), L.dA.k, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_T), coarse, cnc,
                p->d_shifts, omega, kind == MGCMT_GS_MC ? 1 : 0, nsweep, mode, npre, row_lo, row_hi, L.gr - 1 - L.r0, k, p->fused_rows,
                out_lo, out_hi);
@@ -281,8 +283,15 @@ bool fused_level(const mgcmt_plan* p, int l, int kind) {
 }
 
 int pass_sweeps(const mgcmt_plan* p, int l, int kind, int left) {
-  const int cap = fused_max_sweeps(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0, p->levels[l].nr != p->levels[l].gr);
+  const int cap = fused_max_sweeps(p->levels[l].dA.k, kind == MGCMT_GS_MC ? 1 : 0);
   return left < cap ? left : cap;
+}
+
+int exchanged_rows(const mgcmt_plan* p, int l) {
+  const Level& L = p->levels[l];
+  const KOp& k = L.dA.k;
+  const int want = (k.five_point || k.five_diag) ? 8 : 10;
+  return want < L.halo ? want : L.halo;
 }
 }  // namespace mgcmt
 namespace {
@@ -304,6 +313,9 @@ int lex_sweep(mgcmt_plan* p, int l, int slot, double alpha, double beta, double 
     const size_t need_scan = (size_t)lex_wave_carry(g, p->nvec, nsweeps), need_band = (size_t)p->nvec * lex_band_count(g) * lex_band_stride(g);
     const size_t need_carry = band ? need_band : need_scan, need_sync = 2 + 4 * (size_t)p->nvec * blocks;  // (2 words used; the rest is the diagnostic build's per-block record)
     if (need_carry > p->lex_carry_doubles || need_sync > p->lex_sync_words) {
+      // cached cycle graphs hold the old scratch pointers in their memset / kernel nodes: they go before the buffers do
+      // (a graph replayed after this point would write through freed memory)
+      p->graphs_invalidate();
       MG_HIP(hipStreamSynchronize(s));
       if (p->lex_carry) (void)hipFree(p->lex_carry);
       if (p->lex_sync) (void)hipFree(p->lex_sync);
@@ -762,7 +774,8 @@ int mgcmt_plan_create(const mgcmt_plan_desc* d, mgcmt_plan** out) {
       L.r0 = 0;
       L.nr = L.gr;
     }
-    L.stride = ((L.nr + 2 * kHalo) * L.gc + 31) / 32 * 32;
+    L.halo = d->dim == 2 ? kHalo : 1;
+    L.stride = ((L.nr + 2 * L.halo) * L.gc + 31) / 32 * 32;
     auto build = [&](HostOp& h, const HostOp* finer, int nterms, const double* xf, const double* yf) {
       h.nterms = nterms;
       h.X.resize(nterms);
@@ -856,6 +869,13 @@ int mgcmt_plan_get_factors(const mgcmt_plan* p, int op, int l, int which, double
   return MGCMT_OK;
 }
 
+int mgcmt_plan_level_halo(const mgcmt_plan* p, int l, int* halo_rows, int* exchanged) {
+  MG_TRY(check_level(p, l));
+  if (halo_rows) *halo_rows = p->levels[l].halo;
+  if (exchanged) *exchanged = exchanged_rows(p, l);
+  return MGCMT_OK;
+}
+
 int mgcmt_vec_ptr(const mgcmt_plan* p, int l, int slot, int vec, void** device_ptr) {
   MG_TRY(check_vec(p, l, slot, vec));
   if (!device_ptr) return fail(MGCMT_ERR_INVALID, "null pointer");
@@ -900,7 +920,7 @@ int mgcmt_zero(mgcmt_plan* p, int l, int slot, int vec, void* stream) {
   MG_TRY(check_vec(p, l, slot, vec));
   MG_TRY(ensure_slot(p, l, slot));
   const Level& L = p->levels[l];
-  MG_HIP(hipMemsetAsync(p->kvec(l, slot, vec).p - (long)kHalo * L.gc, 0, sizeof(double) * (size_t)(L.nr + 2 * kHalo) * L.gc, S(stream)));
+  MG_HIP(hipMemsetAsync(p->kvec(l, slot, vec).p - (long)L.halo * L.gc, 0, sizeof(double) * (size_t)(L.nr + 2 * L.halo) * L.gc, S(stream)));
   return MGCMT_OK;
 }
 
@@ -966,6 +986,8 @@ int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int 
     // the coarsest-level factorisation depends on the shift VALUES; redo it eagerly when they changed
     MG_TRY(ensure_coarse_factor(p, (int)p->levels.size() - 1, k, s));
     MG_HIP(hipGraphLaunch(hit->second.exec, s));
+    // a replayed cycle runs the wave pipeline too: the next synchronising call must look at its error word
+    if (hit->second.lex_wave) p->lex_wave_used = true;
     size_t i = 0;
     for (Level& L : p->levels) {
       L.base[MGCMT_SLOT_V] = hit->second.post_state[i++];
@@ -986,7 +1008,11 @@ int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int 
     (void)hipGetLastError();
     return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, cycle_flags, s);
   }
+  const bool lex_before = p->lex_wave_used;
+  p->lex_wave_used = false;
   const int rc = vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, cycle_flags, p->capture_stream);
+  const bool lex_captured = p->lex_wave_used;  // the captured body launches a wave-pipeline sweep
+  p->lex_wave_used = lex_before || lex_captured;
   hipGraph_t graph = nullptr;
   const hipError_t end = hipStreamEndCapture(p->capture_stream, &graph);
   if (rc != MGCMT_OK || end != hipSuccess || !graph) {
@@ -996,6 +1022,7 @@ int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int 
     return rc != MGCMT_OK ? rc : fail(MGCMT_ERR_HIP, "graph capture of the V-cycle failed");
   }
   mgcmt_plan::CycleGraph cg;
+  cg.lex_wave = lex_captured;
   const hipError_t inst = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
   if (inst != hipSuccess) {
@@ -1252,7 +1279,7 @@ int mgcmt_normalize(mgcmt_plan* p, int l, int slot, int k, void* stream) {
   return post_launch();
 }
 
-int mgcmt_fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, void* stream) {
+static int fused_pass_checked(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, hipStream_t s, int reps) {
   MG_TRY(check_level(p, l));
   MG_TRY(check_k(p, k));
   if (!fused_level(p, l, kind)) return fail(MGCMT_ERR_UNSUPPORTED, "level / smoother not covered by the fused kernels");
@@ -1269,8 +1296,30 @@ int mgcmt_fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, i
     MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_V));
     MG_TRY(ensure_slot(p, l + 1, MGCMT_SLOT_F));
   }
-  MG_TRY(fused_pass(p, l, kind, nsweep, omega, mode & 15, k, S(stream), npre));
+  for (int r = 0; r < reps; ++r) MG_TRY(fused_pass(p, l, kind, nsweep, omega, mode & 15, k, s, npre));
   return post_launch();
+}
+
+int mgcmt_fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, void* stream) {
+  return fused_pass_checked(p, l, kind, nsweep, omega, mode, k, S(stream), 1);
+}
+
+int mgcmt_time_fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int reps, double* ms_out, void* stream) {
+  if (!ms_out || reps < 1) return fail(MGCMT_ERR_INVALID, "bad arguments");
+  MG_TRY(fused_pass_checked(p, l, kind, nsweep, omega, mode, 1, S(stream), 1));  // (allocations, occupancy query: untimed)
+  hipEvent_t a, b;
+  MG_HIP(hipEventCreate(&a));
+  MG_HIP(hipEventCreate(&b));
+  MG_HIP(hipEventRecord(a, S(stream)));
+  const int rc = fused_pass_checked(p, l, kind, nsweep, omega, mode, 1, S(stream), reps);
+  MG_HIP(hipEventRecord(b, S(stream)));
+  MG_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  MG_HIP(hipEventElapsedTime(&ms, a, b));
+  *ms_out = (double)ms / reps;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return rc;
 }
 
 int mgcmt_fused_max_sweeps(const mgcmt_plan* p, int l, int kind, int* max_sweeps) {

@@ -46,6 +46,7 @@ struct Level {
   int64_t gr = 1, gc = 1;  // global rows / cols
   int64_t r0 = 0, nr = 1;  // local strip
   int64_t stride = 0;      // elements between vectors (halo rows included)
+  int halo = kHalo;        // halo rows above and below every vector: kHalo on 2-D levels, 1 on 1-D levels (a "row" is the whole vector)
   double* base[4] = {nullptr, nullptr, nullptr, nullptr};  // allocation start per slot
   HostOp hA, hM;
   DevOp dA, dM;
@@ -90,6 +91,7 @@ struct mgcmt_plan {
   struct CycleGraph {
     hipGraphExec_t exec = nullptr;
     std::vector<double*> post_state;  // base pointers of slots V and T of every level after the cycle
+    bool lex_wave = false;            // the captured body runs the lexicographic wave pipeline (its error word must be checked after a replay)
   };
   std::map<std::string, CycleGraph> graphs;
   std::map<std::string, int> cycle_seen;
@@ -109,7 +111,7 @@ struct mgcmt_plan {
   mgcmt::KVec kvec(int l, int slot, int vec = 0) const {
     using namespace mgcmt;
     const Level& L = levels[l];
-    return KVec{L.base[slot] + (long)kHalo * L.gc + (long)vec * L.stride, (long)L.stride};
+    return KVec{L.base[slot] + (long)L.halo * L.gc + (long)vec * L.stride, (long)L.stride};
   }
   long interior(int l) const { return (long)levels[l].nr * levels[l].gc; }
 };
@@ -122,6 +124,9 @@ int ensure_slot(mgcmt_plan* p, int l, int slot);
 int post_launch();
 bool fused_level(const mgcmt_plan* p, int l, int kind);
 int pass_sweeps(const mgcmt_plan* p, int l, int kind, int left);
+// halo rows of level l that a sharded cycle exchanges and its passes read (<= the level's halo): 8 behind a 5-point
+// operator (at most eight stages per pass), 10 behind a 9-point one (two four-colour sweeps + the restriction: nine)
+int exchanged_rows(const mgcmt_plan* p, int l);
 // one fused pass V -> T (then swapped); [out_lo, out_hi) = the rows produced (default: the whole strip), swap = false
 // leaves the buffer roles alone (the caller issues the other row ranges of the same pass and swaps once)
 int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, hipStream_t s, int npre = 0,

@@ -113,7 +113,9 @@ struct ShardComm {
   bool overlap = true;    // RCCL transport only
   int split = 1;          // boundary rows first (both transports): 1 on strips of >= 2^22 points, 2 always (tests), 0 never
   bool self_ring = false; // one-rank self-test: the rank is its own neighbour above and below in every exchange
-  double* d_red = nullptr;
+  int emulate_of = 0;     // > 1 on a ONE-rank communicator in self-ring mode: the plan is rank R's strip of an N-rank job (timing rehearsal)
+  double* d_red = nullptr;  // [2 * kMaxVec] reduction results (inner products of the sharded Gram-Schmidt, mgcmt_allreduce_sum)
+  std::vector<double> h_red;
 };
 
 void comm_release(mgcmt_plan* p) {
@@ -133,8 +135,13 @@ void comm_release(mgcmt_plan* p) {
 namespace {
 
 constexpr int kRing = 0x100;       // mgcmt_halo_exchange: treat a ONE-rank chain as a ring (transport self-test)
-constexpr long kBoundaryRows = 2 * kHalo;  // rows of a strip's edge produced first: the neighbour's halo rows of V and,
-                                           // restricted, of the coarse right-hand side
+// Rows of a strip's edge produced first by a split pass: what the neighbour's next pass reads of V (the level's
+// exchanged rows) and, restricted, of the coarse right-hand side (twice the coarse level's exchanged rows).
+long boundary_rows(const mgcmt_plan* p, int l, bool sends_f) {
+  long b = exchanged_rows(p, l);
+  if (sends_f && 2L * exchanged_rows(p, l + 1) > b) b = 2L * exchanged_rows(p, l + 1);
+  return (b + 1) & ~1L;
+}
 
 struct Msg {
   double* ptr;
@@ -149,34 +156,38 @@ int check_comm(const mgcmt_plan* p) {
   return MGCMT_OK;
 }
 
-// boundary rows out / halo rows in of vector 0 of (level, slot) for the chain neighbours
-int halo_msgs(mgcmt_plan* p, int l, int slot, bool ring, std::vector<Msg>* out) {
+// boundary rows out / halo rows in of vectors 0..k-1 of (level, slot) for the chain neighbours: the level's exchanged
+// rows (exchanged_rows: 8 behind a 5-point operator, 10 behind a 9-point one), next to the strip
+int halo_msgs(mgcmt_plan* p, int l, int slot, bool ring, int k, std::vector<Msg>* out) {
   const ShardComm* c = p->comm;
   MG_TRY(ensure_slot(p, l, slot));
   const Level& L = p->levels[l];
   if (L.nr == L.gr && !ring) return MGCMT_OK;  // not a strip level: nothing to exchange
-  if (L.nr < kHalo) return fail(MGCMT_ERR_INVALID, "strip has fewer rows than the halo");
-  const size_t cnt = (size_t)kHalo * L.gc;
-  double* v = p->kvec(l, slot).p;
-  double* top = v;
-  double* bottom = v + (long)(L.nr - kHalo) * L.gc;
-  double* halo_up = v - (long)kHalo * L.gc;
-  double* halo_dn = v + (long)L.nr * L.gc;
-  if (ring) {  // one rank, itself above and below: messages to one peer match in order
-    out->push_back({bottom, cnt, 0, true});
-    out->push_back({top, cnt, 0, true});
-    out->push_back({halo_up, cnt, 0, false});
-    out->push_back({halo_dn, cnt, 0, false});
-    return MGCMT_OK;
-  }
-  const int up = c->rank - 1, down = c->rank + 1;
-  if (up >= 0) {
-    out->push_back({top, cnt, up, true});
-    out->push_back({halo_up, cnt, up, false});
-  }
-  if (down < c->nranks) {
-    out->push_back({bottom, cnt, down, true});
-    out->push_back({halo_dn, cnt, down, false});
+  const long hx = exchanged_rows(p, l);
+  if (L.nr < hx) return fail(MGCMT_ERR_INVALID, "strip has fewer rows than the halo");
+  const size_t cnt = (size_t)hx * L.gc;
+  for (int q = 0; q < k; ++q) {
+    double* v = p->kvec(l, slot, q).p;
+    double* top = v;
+    double* bottom = v + (long)(L.nr - hx) * L.gc;
+    double* halo_up = v - (long)hx * L.gc;
+    double* halo_dn = v + (long)L.nr * L.gc;
+    if (ring) {  // one rank, itself above and below: messages to one peer match in order
+      out->push_back({bottom, cnt, 0, true});
+      out->push_back({top, cnt, 0, true});
+      out->push_back({halo_up, cnt, 0, false});
+      out->push_back({halo_dn, cnt, 0, false});
+      continue;
+    }
+    const int up = c->rank - 1, down = c->rank + 1;
+    if (up >= 0) {
+      out->push_back({top, cnt, up, true});
+      out->push_back({halo_up, cnt, up, false});
+    }
+    if (down < c->nranks) {
+      out->push_back({bottom, cnt, down, true});
+      out->push_back({halo_dn, cnt, down, false});
+    }
   }
   return MGCMT_OK;
 }
@@ -187,11 +198,15 @@ int run_msgs(mgcmt_plan* p, const std::vector<Msg>& msgs, hipStream_t s) {
   if (c->nccl) {
     RcclApi* api = rccl();
     MG_RCCL(api, api->GroupStart());
+    // an error inside the group must not leave it open (every later RCCL call of the process would queue behind it)
+    int bad = kRcclSuccess;
     for (const Msg& m : msgs) {
-      if (m.send) MG_RCCL(api, api->Send(m.ptr, m.count, kRcclFloat64, m.peer, c->nccl, s));
-      else MG_RCCL(api, api->Recv(m.ptr, m.count, kRcclFloat64, m.peer, c->nccl, s));
+      bad = m.send ? api->Send(m.ptr, m.count, kRcclFloat64, m.peer, c->nccl, s) : api->Recv(m.ptr, m.count, kRcclFloat64, m.peer, c->nccl, s);
+      if (bad != kRcclSuccess) break;
     }
-    MG_RCCL(api, api->GroupEnd());
+    const int end = api->GroupEnd();
+    if (bad != kRcclSuccess) return fail(MGCMT_ERR_HIP, std::string("ncclSend/ncclRecv: ") + (api->GetErrorString ? api->GetErrorString(bad) : "rccl error"));
+    MG_RCCL(api, end);
     return MGCMT_OK;
   }
   if (!c->p2p) return fail(MGCMT_ERR_INVALID, "communicator has no point-to-point transport");
@@ -213,50 +228,99 @@ int join_exchange(mgcmt_plan* p, hipStream_t s) {
 }
 
 // One fused pass on strip level l whose products the neighbours need next: V' boundary rows (unless the pass stores
-// nothing) and, after a restriction, the coarse right-hand side's boundary rows (when level l+1 is a strip level too).
-// Boundary rows first, their exchange beside the interior rows.
-int strip_pass(mgcmt_plan* p, int l, int kind, int n, double omega, int mode, int npre, hipStream_t s, bool coarse_is_strip) {
+// nothing, or the caller exchanges V itself after a Gram-Schmidt: exchange_v = false) and, after a restriction, the
+// coarse right-hand side's boundary rows (when level l+1 is a strip level too).  Boundary rows first, their exchange
+// beside the interior rows.
+int strip_pass(mgcmt_plan* p, int l, int kind, int n, double omega, int mode, int npre, int k, hipStream_t s, bool coarse_is_strip,
+               bool exchange_v = true) {
   ShardComm* c = p->comm;
   Level& L = p->levels[l];
   MG_TRY(join_exchange(p, s));
-  const bool stores_v = !(mode & 8);
+  const bool stores_v = !(mode & 8) && exchange_v;
   const bool sends_f = (mode & 3) == 2 && coarse_is_strip;
   const bool ring = c->self_ring;
   const bool up = c->rank > 0 || ring, down = c->rank + 1 < c->nranks || ring;
-  const long B = kBoundaryRows;
+  const long B = boundary_rows(p, l, sends_f);
   // two extra launches cost about 10 us on the stream; the exchange they free from the critical path is worth more than
   // that only on strips whose interior launch is long enough to hide it (c->split == 2: always, for tests)
-  const bool big = c->split == 2 || (long)L.nr * L.gc >= (1L << 22);
+  const bool big = c->split == 2 || (long)L.nr * L.gc * k >= (1L << 22);
   const bool split = c->split && big && (stores_v || sends_f) && (up || down) && L.nr >= 4 * B;
   std::vector<Msg> msgs;
   if (!split) {
-    MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre));
-    if (stores_v) MG_TRY(halo_msgs(p, l, MGCMT_SLOT_V, ring, &msgs));
-    if (sends_f) MG_TRY(halo_msgs(p, l + 1, MGCMT_SLOT_F, ring, &msgs));
+    MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre));
+    if (stores_v) MG_TRY(halo_msgs(p, l, MGCMT_SLOT_V, ring, k, &msgs));
+    if (sends_f) MG_TRY(halo_msgs(p, l + 1, MGCMT_SLOT_F, ring, k, &msgs));
     return run_msgs(p, msgs, s);
   }
   const long lo = up ? B : 0, hi = down ? L.nr - B : L.nr;
-  if (up) MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre, 0, B, false));
-  if (down) MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre, L.nr - B, L.nr, false));
+  if (up) MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, 0, B, false));
+  if (down) MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, L.nr - B, L.nr, false));
   // the messages name the buffer the pass writes: V' lives in slot T until the roles are swapped below
   if (stores_v) {
     std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
-    const int rc = halo_msgs(p, l, MGCMT_SLOT_V, ring, &msgs);
+    const int rc = halo_msgs(p, l, MGCMT_SLOT_V, ring, k, &msgs);
     std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
     MG_TRY(rc);
   }
-  if (sends_f) MG_TRY(halo_msgs(p, l + 1, MGCMT_SLOT_F, ring, &msgs));
+  if (sends_f) MG_TRY(halo_msgs(p, l + 1, MGCMT_SLOT_F, ring, k, &msgs));
   if (c->nccl && c->overlap) {
     MG_HIP(hipEventRecord(c->ev_boundary, s));
     MG_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
     MG_TRY(run_msgs(p, msgs, c->comm_stream));
     MG_HIP(hipEventRecord(c->ev_done, c->comm_stream));
     c->pending = true;
-    MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre, lo, hi, true));
+    MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, lo, hi, true));
     return MGCMT_OK;
   }
-  MG_TRY(fused_pass(p, l, kind, n, omega, mode, 1, s, npre, lo, hi, true));
+  MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, lo, hi, true));
   return run_msgs(p, msgs, s);
+}
+
+// sum over ranks of n <= 2 * kMaxVec doubles at c->d_red, in stream order (RCCL) or through the host (callbacks)
+int allreduce_device(mgcmt_plan* p, int n, hipStream_t s) {
+  ShardComm* c = p->comm;
+  if (c->nranks == 1 || n < 1) return MGCMT_OK;
+  if (c->nccl) {
+    RcclApi* api = rccl();
+    MG_RCCL(api, api->AllReduce(c->d_red, c->d_red, (size_t)n, kRcclFloat64, kRcclSum, c->nccl, s));
+    return MGCMT_OK;
+  }
+  if (!c->allreduce) return fail(MGCMT_ERR_INVALID, "communicator has no all-reduce transport");
+  c->h_red.resize(2 * kMaxVec);
+  MG_HIP(hipMemcpyAsync(c->h_red.data(), c->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  MG_HIP(hipStreamSynchronize(s));
+  if (c->allreduce(c->user, c->h_red.data(), n) != 0) return fail(MGCMT_ERR_HIP, "external all-reduce transport failed");
+  MG_HIP(hipMemcpyAsync(c->d_red, c->h_red.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+  MG_HIP(hipStreamSynchronize(s));  // (h_red is reused by the next step)
+  return MGCMT_OK;
+}
+
+// Modified Gram-Schmidt (MGCMTProcessor.py:44-50) of the k columns of slot V on strip level l: the single plan's one
+// launch per column (k_mgs_step: project column i out of the later ones, normalise it, accumulate the inner products the
+// next column needs), with the inner products summed over the ranks between the steps — ONE all-reduce of the k - i
+// coefficients per column, in stream order.  Every rank ends with the same coefficients, hence with
+// its rows of the same orthonormal columns.
+int sharded_gramschmidt(mgcmt_plan* p, int l, int k, hipStream_t s) {
+  ShardComm* c = p->comm;
+  const long n = p->interior(l);
+  const long stride = p->levels[l].stride;
+  double* a0 = p->kvec(l, MGCMT_SLOT_V, 0).p;
+  double* pa = p->d_partials;
+  const int nb = reduce_blocks(n);
+  launch_dot_partials(s, n, a0, a0, stride, k, pa);  // <a_0, a_t>, t = 0..k-1, this rank's rows
+  launch_final_sums(s, k, nb, pa, c->d_red);
+  MG_TRY(post_launch());
+  MG_TRY(allreduce_device(p, k, s));
+  for (int i = 0; i < k; ++i) {
+    const int m = k - 1 - i;
+    launch_mgs_step(s, n, c->d_red, a0 + i * stride, stride, m, pa, 1);
+    if (m > 0) {
+      launch_final_sums(s, m, nb, pa, c->d_red);
+      MG_TRY(post_launch());
+      MG_TRY(allreduce_device(p, m, s));
+    }
+  }
+  return post_launch();
 }
 
 std::vector<int> split_sweeps(const mgcmt_plan* p, int l, int kind, int nu) {
@@ -287,7 +351,6 @@ static int comm_common(mgcmt_plan* p, int rank, int nranks, ShardComm** out) {
   if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(MGCMT_ERR_INVALID, "bad rank / nranks");
   if (p->dim != 2) return fail(MGCMT_ERR_UNSUPPORTED, "only 2-D plans are sharded");
-  if (p->nvec != 1) return fail(MGCMT_ERR_UNSUPPORTED, "a sharded plan holds one vector");
   comm_release(p);
   MG_HIP(hipSetDevice(p->device));
   ShardComm* c = new ShardComm();
@@ -298,7 +361,7 @@ static int comm_common(mgcmt_plan* p, int rank, int nranks, ShardComm** out) {
   hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_boundary);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_red, sizeof(double) * 64);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_red, sizeof(double) * 2 * kMaxVec);
   if (e != hipSuccess) {
     comm_release(p);
     return fail(MGCMT_ERR_HIP, std::string("communicator resources: ") + hipGetErrorString(e));
@@ -351,6 +414,11 @@ int mgcmt_comm_set_option(mgcmt_plan* p, int option, int value) {
     if (value && p->comm->nranks != 1) return fail(MGCMT_ERR_INVALID, "the self-ring test mode needs a one-rank communicator");
     p->comm->self_ring = value != 0;
   }
+  else if (option == MGCMT_COMM_OPT_EMULATE_OF) {
+    if (value > 1 && (p->comm->nranks != 1 || !p->comm->self_ring))
+      return fail(MGCMT_ERR_INVALID, "rank emulation needs a one-rank communicator in self-ring mode");
+    p->comm->emulate_of = value > 1 ? value : 0;
+  }
   else return fail(MGCMT_ERR_INVALID, "unknown communicator option");
   return MGCMT_OK;
 }
@@ -363,15 +431,18 @@ int mgcmt_halo_exchange(mgcmt_plan* p, int l, int slot_mask, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   MG_TRY(join_exchange(p, s));
   std::vector<Msg> msgs;
+  const int k = (slot_mask >> 16) & 0xff ? (slot_mask >> 16) & 0xff : 1;  // bits 16-23: vectors 0..k-1 (0 = one)
+  if (k > p->nvec) return fail(MGCMT_ERR_INVALID, "halo exchange of more vectors than the plan holds");
   for (int slot = 0; slot < 4; ++slot)
-    if (slot_mask & (1 << slot)) MG_TRY(halo_msgs(p, l, slot, ring, &msgs));
+    if (slot_mask & (1 << slot)) MG_TRY(halo_msgs(p, l, slot, ring, k, &msgs));
   return run_msgs(p, msgs, s);
 }
 
-int mgcmt_gather_coarse(mgcmt_plan* p, int l, int slot, mgcmt_plan* coarse, int dst_slot, void* stream) {
+int mgcmt_gather_coarse(mgcmt_plan* p, int l, int slot, mgcmt_plan* coarse, int dst_slot, int k, void* stream) {
   MG_TRY(check_comm(p));
   if (!coarse) return fail(MGCMT_ERR_INVALID, "null coarse plan");
   if (l < 0 || l >= (int)p->levels.size()) return fail(MGCMT_ERR_INVALID, "level out of range");
+  if (k < 1 || k > p->nvec || k > coarse->nvec) return fail(MGCMT_ERR_INVALID, "k must be in 1..nvec of both plans");
   ShardComm* c = p->comm;
   hipStream_t s = (hipStream_t)stream;
   MG_TRY(join_exchange(p, s));
@@ -379,29 +450,41 @@ int mgcmt_gather_coarse(mgcmt_plan* p, int l, int slot, mgcmt_plan* coarse, int 
   MG_TRY(ensure_slot(coarse, 0, dst_slot));
   const Level& L = p->levels[l];
   const Level& C = coarse->levels[0];
-  if (C.nr != C.gr || C.gc != L.gc || L.nr * c->nranks != C.gr)
+  const int parts = c->emulate_of > 1 ? c->emulate_of : c->nranks;
+  if (C.nr != C.gr || C.gc != L.gc || L.nr * parts != C.gr)
     return fail(MGCMT_ERR_INVALID, "coarse plan's finest level is not the whole grid of this strip level");
   const size_t cnt = (size_t)L.nr * L.gc;
-  double* mine = p->kvec(l, slot).p;
-  double* whole = coarse->kvec(0, dst_slot).p;
   if (c->nranks == 1) {
-    MG_HIP(hipMemcpyAsync(whole, mine, cnt * sizeof(double), hipMemcpyDeviceToDevice, s));
+    // one rank: a copy.  Emulating rank R of N (timing rehearsal): the own strip lands where rank R's would, and stands
+    // in for the other ranks' strips too, so that the redundant coarse sub-cycle works on data of the right kind
+    for (int q = 0; q < k; ++q)
+      for (int part = 0; part < parts; ++part)
+        MG_HIP(hipMemcpyAsync(coarse->kvec(0, dst_slot, q).p + (size_t)part * cnt, p->kvec(l, slot, q).p, cnt * sizeof(double),
+                              hipMemcpyDeviceToDevice, s));
     return MGCMT_OK;
   }
   if (c->nccl) {
     RcclApi* api = rccl();
-    MG_RCCL(api, api->AllGather(mine, whole, cnt, kRcclFloat64, c->nccl, s));
+    if (k > 1) MG_RCCL(api, api->GroupStart());
+    int bad = kRcclSuccess;
+    for (int q = 0; q < k && bad == kRcclSuccess; ++q)
+      bad = api->AllGather(p->kvec(l, slot, q).p, coarse->kvec(0, dst_slot, q).p, cnt, kRcclFloat64, c->nccl, s);
+    const int end = k > 1 ? api->GroupEnd() : kRcclSuccess;
+    if (bad != kRcclSuccess) return fail(MGCMT_ERR_HIP, std::string("ncclAllGather: ") + (api->GetErrorString ? api->GetErrorString(bad) : "rccl error"));
+    MG_RCCL(api, end);
     return MGCMT_OK;
   }
   if (!c->allgather) return fail(MGCMT_ERR_INVALID, "communicator has no all-gather transport");
   MG_HIP(hipStreamSynchronize(s));
-  if (c->allgather(c->user, mine, whole, (int64_t)cnt) != 0) return fail(MGCMT_ERR_HIP, "external all-gather transport failed");
+  for (int q = 0; q < k; ++q)
+    if (c->allgather(c->user, p->kvec(l, slot, q).p, coarse->kvec(0, dst_slot, q).p, (int64_t)cnt) != 0)
+      return fail(MGCMT_ERR_HIP, "external all-gather transport failed");
   return MGCMT_OK;
 }
 
 int mgcmt_allreduce_sum(mgcmt_plan* p, double* host_inout, int n, void* stream) {
   MG_TRY(check_comm(p));
-  if (!host_inout || n < 1 || n > 64) return fail(MGCMT_ERR_INVALID, "allreduce: 1..64 values");
+  if (!host_inout || n < 1 || n > 2 * kMaxVec) return fail(MGCMT_ERR_INVALID, "allreduce: 1..64 values");
   ShardComm* c = p->comm;
   hipStream_t s = (hipStream_t)stream;
   if (c->nranks == 1) return MGCMT_OK;
@@ -418,17 +501,22 @@ int mgcmt_allreduce_sum(mgcmt_plan* p, double* host_inout, int n, void* stream) 
   return MGCMT_OK;
 }
 
-// One V(nu1,nu2) cycle of the sharded hierarchy: `p` holds levels 0 .. ls-1 as row strips (and level ls as the strip
-// buffer the last restriction writes and the first prolongation reads), `coarse` holds the grid of level ls WHOLE on
-// every rank.  MGCMTSolver.py:281-329 with its recursion unrolled; weighted Jacobi and multicolour Gauss-Seidel are
-// order-independent, so this is the single-GPU cycle's arithmetic.
-int mgcmt_sharded_vcycle(mgcmt_plan* p, mgcmt_plan* coarse, int nu1, int nu2, int nu_coarse, int kind, double omega, int flags,
+// One V(nu1,nu2) cycle of the sharded hierarchy on k vectors: `p` holds levels 0 .. ls-1 as row strips (and level ls as
+// the strip buffer the last restriction writes and the first prolongation reads), `coarse` holds the grid of level ls
+// WHOLE on every rank.  MGCMTSolver.py:281-329 (k = 1) / :375-436 (vcycle_matrix: k columns with their own shifts and,
+// with MGCMT_SHARDED_GRAM_SCHMIDT, the modified Gram-Schmidt of :434 on every level on the way up) with the recursion
+// unrolled; weighted Jacobi and multicolour Gauss-Seidel are order-independent, so this is the single-GPU cycle's
+// arithmetic (the Gram-Schmidt's inner products are summed rank by rank: equal to rounding).
+int mgcmt_sharded_vcycle(mgcmt_plan* p, mgcmt_plan* coarse, int nu1, int nu2, int nu_coarse, int kind, double omega, int k, int flags,
                          void* stream) {
   MG_TRY(check_comm(p));
   if (!coarse) return fail(MGCMT_ERR_INVALID, "null coarse plan");
   if (kind != MGCMT_WJACOBI && kind != MGCMT_GS_MC)
     return fail(MGCMT_ERR_UNSUPPORTED, "only weighted Jacobi and multicolour Gauss-Seidel shard; lexicographic sweeps are sequential");
   if (nu1 < 1 || nu2 < 1 || nu_coarse < 1) return fail(MGCMT_ERR_INVALID, "the sharded cycle needs at least one sweep per leg");
+  if (k < 1 || k > p->nvec || k > coarse->nvec) return fail(MGCMT_ERR_INVALID, "k must be in 1..nvec of both plans");
+  if (flags & ~(MGCMT_SHARDED_V_HALO_VALID | MGCMT_SHARDED_F_HALO_VALID | MGCMT_SHARDED_GRAM_SCHMIDT)) return fail(MGCMT_ERR_INVALID, "unknown flag");
+  const bool gram_schmidt = (flags & MGCMT_SHARDED_GRAM_SCHMIDT) != 0;
   const int ls = (int)p->levels.size() - 1;  // strip levels 0 .. ls-1
   if (ls < 1) return fail(MGCMT_ERR_INVALID, "strip plan has no level below the finest one");
   ShardComm* c = p->comm;
@@ -439,13 +527,14 @@ int mgcmt_sharded_vcycle(mgcmt_plan* p, mgcmt_plan* coarse, int nu1, int nu2, in
     if (l < ls) MG_TRY(ensure_slot(p, l, MGCMT_SLOT_T));
     if (l < ls && !fused_level(p, l, kind)) return fail(MGCMT_ERR_UNSUPPORTED, "a strip level is not covered by the fused kernels");
   }
+  const int ring_bit = c->self_ring ? kRing : 0;
   // what the first pass reads from the neighbours: V (unless the caller vouches that nothing changed it since the
   // previous sharded cycle, whose last pass exchanged it) and, once per right-hand side, F
   {
     int mask = 0;
     if (!(flags & MGCMT_SHARDED_V_HALO_VALID)) mask |= 1 << MGCMT_SLOT_V;
     if (!(flags & MGCMT_SHARDED_F_HALO_VALID)) mask |= 1 << MGCMT_SLOT_F;
-    if (mask) MG_TRY(mgcmt_halo_exchange(p, 0, mask | (c->self_ring ? kRing : 0), stream));
+    if (mask) MG_TRY(mgcmt_halo_exchange(p, 0, mask | ring_bit | (k << 16), stream));
   }
   std::vector<int> recompute(ls, 0);
   std::vector<char> still_zero(ls, 0);
@@ -466,30 +555,38 @@ int mgcmt_sharded_vcycle(mgcmt_plan* p, mgcmt_plan* coarse, int nu1, int nu2, in
         recompute[l] = passes[i];
         still_zero[l] = zero_in;
       }
-      MG_TRY(strip_pass(p, l, kind, passes[i], omega, mode | (zero_in ? 4 : 0), 0, s, l + 1 < ls));
+      MG_TRY(strip_pass(p, l, kind, passes[i], omega, mode | (zero_in ? 4 : 0), 0, k, s, l + 1 < ls));
     }
   }
   // the coarse problem: all-gather, the same sub-cycle on every rank, own rows of the correction with halo rows
-  MG_TRY(mgcmt_gather_coarse(p, ls, MGCMT_SLOT_F, coarse, MGCMT_SLOT_F, stream));
+  MG_TRY(mgcmt_gather_coarse(p, ls, MGCMT_SLOT_F, coarse, MGCMT_SLOT_F, k, stream));
   MG_TRY(ensure_slot(coarse, 0, MGCMT_SLOT_V));
-  MG_TRY(mgcmt_vcycle(coarse, 0, nu_coarse, nu_coarse, nu_coarse, kind, omega, 1, MGCMT_CYCLE_ZERO_START, stream));
+  MG_TRY(mgcmt_vcycle(coarse, 0, nu_coarse, nu_coarse, nu_coarse, kind, omega, k,
+                      MGCMT_CYCLE_ZERO_START | (gram_schmidt ? MGCMT_CYCLE_GRAM_SCHMIDT : 0), stream));
   {
     const Level& L = p->levels[ls];
     const long total = L.gr;
-    const long lo = std::max<long>(L.r0 - kHalo, 0), hi = std::min<long>(L.r0 + L.nr + kHalo, total);
-    MG_HIP(hipMemcpyAsync(p->kvec(ls, MGCMT_SLOT_V).p + (lo - L.r0) * L.gc, coarse->kvec(0, MGCMT_SLOT_V).p + lo * L.gc,
-                          sizeof(double) * (size_t)(hi - lo) * L.gc, hipMemcpyDeviceToDevice, s));
+    const long lo = std::max<long>(L.r0 - L.halo, 0), hi = std::min<long>(L.r0 + L.nr + L.halo, total);
+    for (int q = 0; q < k; ++q)
+      MG_HIP(hipMemcpyAsync(p->kvec(ls, MGCMT_SLOT_V, q).p + (lo - L.r0) * L.gc, coarse->kvec(0, MGCMT_SLOT_V, q).p + lo * L.gc,
+                            sizeof(double) * (size_t)(hi - lo) * L.gc, hipMemcpyDeviceToDevice, s));
   }
   for (int l = ls - 1; l >= 0; --l) {
     const std::vector<int> passes = split_sweeps(p, l, kind, l == 0 ? nu2 : nu_coarse);
     for (size_t i = 0; i < passes.size(); ++i) {
       const int mode = i == 0 ? (1 | (still_zero[l] ? 4 : 0)) : 0;
-      MG_TRY(strip_pass(p, l, kind, passes[i], omega, mode, i == 0 ? recompute[l] : 0, s, false));
+      // with a Gram-Schmidt behind the level's last pass every value of V changes once more: V travels after it
+      const bool exchange_v = !(gram_schmidt && i + 1 == passes.size());
+      MG_TRY(strip_pass(p, l, kind, passes[i], omega, mode, i == 0 ? recompute[l] : 0, k, s, false, exchange_v));
+    }
+    if (gram_schmidt) {
+      MG_TRY(join_exchange(p, s));
+      MG_TRY(sharded_gramschmidt(p, l, k, s));
+      MG_TRY(mgcmt_halo_exchange(p, l, (1 << MGCMT_SLOT_V) | ring_bit | (k << 16), stream));
     }
   }
   // leave nothing running beside the caller's stream
   MG_TRY(join_exchange(p, s));
-  (void)c;
   return post_launch();
 }
 

@@ -125,38 +125,50 @@ class _TorchTransport:
 
 
 class ShardedPlan:
-    def __init__(self, op, lowest, rank, world, device=0, switch_grid=None, on_gpu=True, transport="torch", unique_id=None):
+    """nvec: columns held (vcycle_matrix's k, each with its own shift).  emulate=(R, N): a ONE-rank communicator whose
+    strip plan is rank R's share of an N-rank job — the cycle does that rank's work with itself as both neighbours
+    (MGCMT_COMM_OPT_EMULATE_OF): a timing rehearsal of one rank of N on one GPU, not the N-rank job's numbers."""
+
+    def __init__(self, op, lowest, rank, world, device=0, switch_grid=None, on_gpu=True, transport="torch", unique_id=None, nvec=1,
+                 emulate=None):
         self.rank, self.world, self.on_gpu, self.device = rank, world, on_gpu, device
+        self.nvec = int(nvec)
+        if emulate is not None:
+            if world != 1:
+                raise ValueError("rank emulation runs on a one-rank communicator")
+            erank, world_e = int(emulate[0]), int(emulate[1])
+        else:
+            erank, world_e = rank, world
         if op.dimension != "2d":
             raise ValueError("only 2-D problems are sharded")
         g = op.g
-        if world < 1 or world & (world - 1) or g % world:
+        if world_e < 1 or world_e & (world_e - 1) or g % world_e or not 0 <= erank < world_e:
             raise ValueError("world size must be a power of two dividing the grid")
         nlev_total = _log2(g // lowest) + 1
         if switch_grid is None:
             # below this grid the cycle is cheaper run whole on every rank than as strips with two more exchanges per
             # level: a 2048^2 cycle costs 0.2 ms on one GPU and its all-gather moves 32 MiB; one level up it would be
             # 0.34 ms and 128 MiB (~0.3 ms over xGMI), more than the two exchanges it saves
-            switch_grid = max(2048, 64 * world)
+            switch_grid = max(2048, 64 * world_e)
         # strip levels: grids above the switch size; every strip must keep >= 4*HALO_ROWS rows and even bounds
         ls = 0
-        while ls < nlev_total - 1 and (g >> ls) > switch_grid and ((g >> ls) // world) >= 4 * HALO_ROWS:
+        while ls < nlev_total - 1 and (g >> ls) > switch_grid and ((g >> ls) // world_e) >= 4 * HALO_ROWS:
             ls += 1
         if ls == 0:
-            raise ValueError("grid %d too small to shard over %d ranks (switch grid %d)" % (g, world, switch_grid))
+            raise ValueError("grid %d too small to shard over %d ranks (switch grid %d)" % (g, world_e, switch_grid))
         self.strip_levels = ls                      # levels 0..ls-1 are smoothed as strips
-        rows = g // world
-        self.row_begin, self.row_end = rank * rows, (rank + 1) * rows
+        rows = g // world_e
+        self.row_begin, self.row_end = erank * rows, (erank + 1) * rows
         # the strip plan also holds level `ls` as strips: it is the buffer the last restriction writes into
         # and the first prolongation reads from
-        self.plan = Plan(op, g >> ls, nvec=1, device=device, row_begin=self.row_begin, row_end=self.row_end,
+        self.plan = Plan(op, g >> ls, nvec=self.nvec, device=device, row_begin=self.row_begin, row_end=self.row_end,
                          strip_levels=ls + 1)
         self.g, self.switch = g, g >> ls
         # every rank continues from the switch level on the whole grid (redundantly)
         from .operators import StructuredOperator
         xf, yf = self.plan.factors(ls, 0), self.plan.factors(ls, 1)
         terms = [(xf[m].copy(), yf[m].copy()) for m in range(xf.shape[0])]
-        self.coarse = Plan(StructuredOperator("2d", self.switch, terms), lowest, nvec=1, device=device)
+        self.coarse = Plan(StructuredOperator("2d", self.switch, terms), lowest, nvec=self.nvec, device=device)
         self.transport = transport
         self._torch_transport = None
         L = _lib.lib()
@@ -176,6 +188,11 @@ class ShardedPlan:
             raise ValueError("transport must be 'rccl' or 'torch'")
         self._v_halo_valid = False
         self._f_halo_valid = False
+        self.emulate = None
+        if emulate is not None:
+            self.emulate = (erank, world_e)
+            self.set_comm_option(_lib.COMM_OPT_SELF_RING, 1)
+            self.set_comm_option(_lib.COMM_OPT_EMULATE_OF, world_e)
 
     def _check(self, rc):
         t = self._torch_transport
@@ -188,14 +205,14 @@ class ShardedPlan:
         check(_lib.lib().mgcmt_comm_set_option(self.plan._h, option, int(value)))
 
     # -- communication ------------------------------------------------------------------------------
-    def exchange_halo(self, *pairs, ring=False):
+    def exchange_halo(self, *pairs, ring=False, k=1):
         """Fill the halo rows of every (level, slot) in `pairs` with the neighbours' boundary rows (chain topology);
         one batch per level."""
         by_level = {}
         for level, slot in pairs:
             by_level[level] = by_level.get(level, 0) | (1 << slot)
         for level, mask in sorted(by_level.items()):
-            self._check(_lib.lib().mgcmt_halo_exchange(self.plan._h, level, mask | (_lib.HALO_RING if ring else 0), None))
+            self._check(_lib.lib().mgcmt_halo_exchange(self.plan._h, level, mask | (_lib.HALO_RING if ring else 0) | (k << 16), None))
 
     def allreduce_sum(self, values):
         a = np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy()
@@ -204,16 +221,20 @@ class ShardedPlan:
 
     # -- data ---------------------------------------------------------------------------------------
     def set_shift(self, mu):
-        self.plan.set_shifts([float(mu)])
-        self.coarse.set_shifts([float(mu)])
+        self.set_shifts([float(mu)])
 
-    def upload_local(self, slot, host_rows):
+    def set_shifts(self, shifts):
+        """one shift per column (vcycle_matrix's shifts=, MGCMTSolver.py:385-388)"""
+        self.plan.set_shifts(shifts)
+        self.coarse.set_shifts(shifts)
+
+    def upload_local(self, slot, host_rows, vec=0):
         """This rank's rows of a fine-level vector (host array of local_rows*g doubles)."""
-        self.plan.upload(0, slot, 0, host_rows)
+        self.plan.upload(0, slot, vec, host_rows)
         self.invalidate(slot)
 
-    def fill_local(self, slot, value):
-        self.plan.fill(0, slot, 0, value)
+    def fill_local(self, slot, value, vec=0):
+        self.plan.fill(0, slot, vec, value)
         self.invalidate(slot)
 
     def invalidate(self, slot):
@@ -223,35 +244,46 @@ class ShardedPlan:
         if slot == SLOT_V:
             self._v_halo_valid = False
 
-    def download_local(self, slot):
-        return self.plan.download(0, slot, 0)
+    def download_local(self, slot, vec=0):
+        return self.plan.download(0, slot, vec)
 
     def sync(self):
         self.plan.sync()
 
     # -- the cycle ----------------------------------------------------------------------------------
-    def vcycle(self, nu1, nu2, kind, omega=1.0, nu_coarse=None):
-        """One V(nu1,nu2) cycle on V, F of the fine level (sharded down to the switch grid)."""
+    def vcycle(self, nu1, nu2, kind, omega=1.0, nu_coarse=None, k=1, gram_schmidt=False):
+        """One V(nu1,nu2) cycle on columns 0..k-1 of V, F of the fine level (sharded down to the switch grid);
+        gram_schmidt: vcycle_matrix's modified Gram-Schmidt of the columns on every level on the way up
+        (MGCMTSolver.py:434), its inner products all-reduced over the ranks."""
         if kind not in (WJACOBI, GS_MC):
             raise ValueError("only weighted Jacobi and multicolour Gauss-Seidel shard; lexicographic sweeps are sequential")
         if nu1 < 1 or nu2 < 1:
             raise ValueError("the sharded cycle needs at least one pre- and one post-smoothing sweep")
         nu_coarse = nu1 if nu_coarse is None else nu_coarse
         flags = (_lib.SHARDED_V_HALO_VALID if self._v_halo_valid else 0) | (_lib.SHARDED_F_HALO_VALID if self._f_halo_valid else 0)
+        if gram_schmidt:
+            flags |= _lib.SHARDED_GRAM_SCHMIDT
         self._check(_lib.lib().mgcmt_sharded_vcycle(self.plan._h, self.coarse._h, nu1, nu2, nu_coarse, kind,
-                                                    ctypes.c_double(omega), flags, None))
+                                                    ctypes.c_double(omega), int(k), flags, None))
         self._v_halo_valid = self._f_halo_valid = True
 
-    def residual_norm(self):
-        """|| F - (A - mu I) V ||_2 over all ranks."""
+    def residual_norm(self, vec=0):
+        """|| F - (A - mu I) V ||_2 of column `vec` over all ranks."""
         P = self.plan
         if not self._v_halo_valid:
-            self.exchange_halo((0, SLOT_V))
+            self.exchange_halo((0, SLOT_V), ring=self.emulate is not None, k=self.nvec)
             self._v_halo_valid = True
-        P.apply(0, (SLOT_V, 0), (SLOT_T, 0), with_shift=True)
-        P.axpy(0, -1.0, (SLOT_F, 0), (SLOT_T, 0))
-        local = P.dot(0, (SLOT_T, 0), (SLOT_T, 0))
+        P.apply(0, (SLOT_V, vec), (SLOT_T, vec), with_shift=True)
+        P.axpy(0, -1.0, (SLOT_F, vec), (SLOT_T, vec))
+        local = P.dot(0, (SLOT_T, vec), (SLOT_T, vec))
         return float(self.allreduce_sum([local])[0]) ** 0.5
+
+    def checksum(self, vec=0):
+        """(sum V, sum V*V) of column `vec` over all ranks: what a sharded run and the single plan must agree on."""
+        P = self.plan
+        P.fill(0, SLOT_T, vec, 1.0)
+        local = [P.dot(0, (SLOT_V, vec), (SLOT_T, vec)), P.dot(0, (SLOT_V, vec), (SLOT_V, vec))]
+        return self.allreduce_sum(local)
 
     def close(self):
         self.plan.close()

@@ -11,6 +11,7 @@ back in as the next call's `v0` uploads as one DMA too.
 Page-locked memory is a bounded resource: buffers in use plus buffers on the free list never exceed
 MGCMT_PINNED_POOL_BYTES (default 8 GiB; 0 disables the pool); beyond that — and for arrays below the staging threshold
 of transfer.hip, where none of this matters — `empty` is `numpy.empty`."""
+import collections
 import ctypes
 import os
 import threading
@@ -35,8 +36,23 @@ def _limit():
         return 8 << 30
 
 
+_returned = collections.deque()   # (key, address) of dropped results, not yet on the free list
+
+
 def _release(key, address):
-    with _lock:
+    """Finalizer of a result array.  It may run inside ANY allocation of this thread (a cyclic-GC pass), also one made
+    while `_lock` is held — so it takes no lock: deque.append is atomic, and the entries are folded into `_free` by the
+    next `empty()` / `drain()` / `stats()` under the lock."""
+    _returned.append((key, address))
+
+
+def _fold_returned():
+    """dropped results -> free list (lock held)"""
+    while True:
+        try:
+            key, address = _returned.popleft()
+        except IndexError:
+            return
         _free.setdefault(key, []).append(address)
 
 
@@ -65,6 +81,7 @@ def empty(n):
     lib = _lib.lib()
     key = (id(lib), nbytes)
     with _lock:
+        _fold_returned()
         _libs[id(lib)] = lib
         lst = _free.get(key)
         if lst:
@@ -87,10 +104,12 @@ def empty(n):
 
 def stats():
     with _lock:
+        _fold_returned()
         return dict(_stats, pinned_bytes=_total, free_buffers=sum(len(v) for v in _free.values()))
 
 
 def drain():
     """give every buffer on the free list back to the allocator (tests; a caller that wants the memory back)"""
     with _lock:
+        _fold_returned()
         _trim(0, -1)

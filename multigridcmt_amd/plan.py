@@ -80,6 +80,12 @@ class Plan:
         check(_lib.lib().mgcmt_plan_get_factors(self._h, op, level, which, as_dp(out), out.size))
         return out
 
+    def level_halo(self, level):
+        """(halo rows kept around every vector of `level`, how many of them a sharded cycle exchanges and reads)"""
+        h, x = c_int(0), c_int(0)
+        check(_lib.lib().mgcmt_plan_level_halo(self._h, level, ctypes.byref(h), ctypes.byref(x)))
+        return h.value, x.value
+
     def vec_ptr(self, level, slot, vec=0):
         p = c_void_p()
         check(_lib.lib().mgcmt_vec_ptr(self._h, level, slot, vec, ctypes.byref(p)))
@@ -248,6 +254,12 @@ class Plan:
     def time_smoother(self, level, kind, nu, omega, reps, stream=None):
         ms = c_double(0.0)
         check(_lib.lib().mgcmt_time_smoother(self._h, level, kind, nu, c_double(omega), reps, ctypes.byref(ms), stream))
+        return ms.value
+
+    def time_fused_pass(self, level, kind, nsweep, omega, mode, reps, stream=None):
+        """average milliseconds of one fused pass (mode as fused_pass) over `reps` launches, HIP events on the stream"""
+        ms = c_double(0.0)
+        check(_lib.lib().mgcmt_time_fused_pass(self._h, level, kind, nsweep, c_double(omega), mode, reps, ctypes.byref(ms), stream))
         return ms.value
 
 

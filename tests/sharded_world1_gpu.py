@@ -30,7 +30,6 @@ os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
 g = 4096
-H = _lib.HALO_ROWS
 op = laplacian_operator(g, "2d") * (-1 / np.pi ** 2)
 f = np.random.RandomState(2).rand(g * g)
 
@@ -62,6 +61,8 @@ for transport in ("rccl", "torch"):
         sp.sync()
         for level, cols in ((0, g), (1, g // 2)):
             rows = cols
+            halo, H = sp.plan.level_halo(level)         # rows kept / rows exchanged (8 behind the 5-point operator, 10 behind the 9-point one)
+            assert (halo, H) == (_lib.HALO_ROWS, 8 if level == 0 else 10), (halo, H)
             base = sp.plan.vec_ptr(level, W, 0) - H * cols * 8
             flat = torch.as_tensor(_DevicePointer(base, (rows + 2 * H) * cols), device="cuda:0").cpu().numpy().reshape(rows + 2 * H, cols)
             assert np.array_equal(flat[:H], flat[rows:rows + H]), "upper halo rows != bottom rows (level %d)" % level

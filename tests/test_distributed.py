@@ -127,6 +127,65 @@ def test_sharded_square_well_equals_single_plan(tmp_path, kind_name):
     assert abs(res - want_res) < 1e-9 * want_res
 
 
+def _matrix_worker(rank, world, port, g, kind, omega, nu, k, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hip_cpu_mock")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import build_emu
+    from multigridcmt_amd import _lib
+    _lib.use_library(build_emu.build())
+    from multigridcmt_amd.distributed import ShardedPlan
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sp = ShardedPlan(_operator("laplacian", g), 8, rank, world, switch_grid=g // 4, on_gpu=False, nvec=k)
+    sp.set_shifts(np.linspace(0.1, 0.5, k))
+    sp.set_comm_option(_lib.COMM_OPT_SPLIT, 2)
+    rng = np.random.RandomState(11)
+    F, V0 = rng.rand(k, g * g), rng.rand(k, g * g)
+    rows = g // world
+    sl = slice(rank * rows * g, (rank + 1) * rows * g)
+    for q in range(k):
+        sp.upload_local(_lib.SLOT_F, F[q, sl], vec=q)
+        sp.upload_local(_lib.SLOT_V, V0[q, sl], vec=q)
+    for _ in range(2):
+        sp.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu, k=k, gram_schmidt=True)
+    np.save(os.path.join(out_dir, "part%d.npy" % rank), np.stack([sp.download_local(_lib.SLOT_V, vec=q) for q in range(k)]))
+    sp.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind_name", ["wjacobi", "rb"])
+def test_sharded_vcycle_matrix_equals_single_plan(tmp_path, kind_name):
+    """vcycle_matrix (MGCMTSolver.py:375-436) on strips: k columns with their own shifts, modified Gram-Schmidt on every
+    level on the way up (:434) with the inner products all-reduced over the ranks (one all-reduce of the column's
+    coefficients per column) — against the single plan's cycle with MGCMT_CYCLE_GRAM_SCHMIDT."""
+    import torch.multiprocessing as mp
+    from conftest import bind_backend
+    bind_backend("emu")
+    from multigridcmt_amd import _lib
+    from multigridcmt_amd.plan import Plan
+    g, nu, k, world = 256, 2, 3, 2
+    kind, omega = (_lib.WJACOBI, 2. / 3.) if kind_name == "wjacobi" else (_lib.GS_MC, 1.0)
+    mp.spawn(_matrix_worker, args=(world, _free_port(), g, kind, omega, nu, k, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("part%d.npy" % r)) for r in range(world)], axis=1)
+    p = Plan(_operator("laplacian", g), 8, nvec=k)
+    p.set_shifts(np.linspace(0.1, 0.5, k))
+    rng = np.random.RandomState(11)
+    F, V0 = rng.rand(k, g * g), rng.rand(k, g * g)
+    for q in range(k):
+        p.upload(0, _lib.SLOT_F, q, F[q])
+        p.upload(0, _lib.SLOT_V, q, V0[q])
+    for _ in range(2):
+        p.vcycle(nu, nu, kind, omega=omega, k=k, nu_coarse=nu, gram_schmidt=True)
+    want = np.stack([p.download(0, _lib.SLOT_V, q) for q in range(k)])
+    p.close()
+    assert rel_err(got, want) < 1e-12
+    gram = want @ want.T
+    assert np.abs(gram - np.eye(k)).max() < 1e-12          # (orthonormal columns: what the Gram-Schmidt is for)
+
+
 def _bench_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hip_cpu_mock")):
@@ -162,6 +221,13 @@ def test_multi_rank_bench_line(tmp_path):
         assert key in out, key
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong" and out["config"]["strip_levels"] == 2
     assert out["value"] > 0 and abs(out["value"] - 512 * 512 * 4 * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6) < 1e-6 * out["value"]
+    # the line proves what it timed: residual history, checksum, and rank 0's single-plan run of the same right-hand side
+    assert len(out["residual_reduction_per_cycle"]) == 5 and out["residual_reduction_per_cycle"][-1] < 1e-6
+    par = out["parity_vs_single_plan"]
+    assert par["checked"] and par["ok"], par
+    assert par["max_rel_diff_checksum"] < 1e-12 and par["max_rel_diff_residual_history"] < 1e-9
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
+    assert out["config"]["exchanged_halo_rows_per_level"] == [8, 10]
 
 
 def test_bench_under_torchrun(tmp_path):

@@ -143,3 +143,25 @@ def test_chained_cycle_equals_unchained_at_size(hip_only, g, kind, omega):
         outs.append(np.array(p.download(0, _lib.SLOT_V, 0)))
         p.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_lex_scratch_growth_between_graph_replays(backend):
+    """One plan, lexicographic Gauss-Seidel: V(2,2) three times (eager, capture, replay), then V(4,4) — whose chained
+    sweeps need more pipeline scratch, so the buffers the captured V(2,2) graph points at are reallocated —, then V(2,2)
+    again: the cached graphs must have been dropped with the old buffers (a replay through freed memory otherwise: a
+    memory fault or silent corruption on the GPU).  Every step against the C oracle.  (On the emulation, where graph
+    capture is a stub, this is the same sequence run eagerly.)"""
+    g = 256
+    f = np.random.RandomState(5).rand(g * g)
+    p = Plan(laplacian_operator(g, "2d") * SCALE, 8, nvec=1)
+    p.set_shifts([0.3])
+    p.upload(0, _lib.SLOT_F, 0, f)
+    p.fill(0, _lib.SLOT_V, 0, 0.0)
+    X, Y = st.laplacian_factors(g, "2d", SCALE)
+    v = np.zeros(g * g)
+    for nu in (2, 2, 2, 4, 2, 2, 5, 2):
+        p.vcycle(nu, nu, _lib.GS_LEX, omega=1.0, nu_coarse=nu)
+        v = st.vcycle(X, Y, g, 8, 0.3, st.GS_LEX, v, f, nu, nu, nu, 1.0)
+        got = p.download(0, _lib.SLOT_V, 0)          # (also the synchronising call that looks at the pipeline's error word)
+        assert rel_err(got, v) < 1e-11, nu
+    p.close()
