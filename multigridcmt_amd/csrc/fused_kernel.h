@@ -76,6 +76,8 @@ struct FusedArgs {
   int n_row_chunks, n_col_groups;
   int rows_per_chunk;  // rows a wave marches over (even), plus the overlap
   int out_lo, out_hi;  // local rows this launch produces (even bounds; 0 .. nr for a whole pass)
+  int out_lo2, out_hi2;  // a second row range produced by the same launch (a strip's two edges in one launch); empty: out_lo2 == out_hi2
+  int n_row_chunks1;   // chunks of the first range (the rest cover the second)
   int rows_override;   // tuning: rows per chunk, 0 = automatic (host side only)
   int xcd_balanced;    // workgroup -> tile mapping: 1 = equal shares of the tile list per XCD, 0 = whole column groups per XCD
 };
@@ -569,8 +571,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_fused(FusedArgs a) {
   const double* __restrict__ ec = PROLONG ? a.ec + q * a.cstride : nullptr;
   double* __restrict__ rc = RESTRICT ? a.rc + q * a.cstride : nullptr;
 
-  const int r_begin = a.out_lo + chunk * a.rows_per_chunk;
-  const int r_end = r_begin + a.rows_per_chunk < a.out_hi ? r_begin + a.rows_per_chunk : a.out_hi;
+  const bool second = chunk >= a.n_row_chunks1;  // (wave-uniform)
+  const int r_begin = second ? a.out_lo2 + (chunk - a.n_row_chunks1) * a.rows_per_chunk : a.out_lo + chunk * a.rows_per_chunk;
+  const int range_hi = second ? a.out_hi2 : a.out_hi;
+  const int r_end = r_begin + a.rows_per_chunk < range_hi ? r_begin + a.rows_per_chunk : range_hi;
   const int rstart = r_begin - (S + E);
   const int rstop = r_end + S + XL + 2 * E;  // rows [rstart, rstop) are marched over
   // Dependency cone of the chunk's outputs: stage s is only NEEDED on rows >= cone0 + s (its products on the rows
@@ -1016,8 +1020,9 @@ void launch_one(hipStream_t s, FusedArgs a, int k) {
     else
       resident_blocks = per_cu * prop.multiProcessorCount;
   }
-  const long nrows = a.out_hi - a.out_lo;  // rows this launch produces
-  if (nrows <= 0) return;
+  const long nrows1 = a.out_hi - a.out_lo, nrows2 = a.out_hi2 > a.out_lo2 ? a.out_hi2 - a.out_lo2 : 0;
+  const long nrows = nrows1 + nrows2;  // rows this launch produces
+  if (nrows1 <= 0) return;
   long rows = a.rows_override;
   if (rows <= 0) {
 #ifndef MGCMT_FUSED_FILL
@@ -1031,10 +1036,11 @@ void launch_one(hipStream_t s, FusedArgs a, int k) {
     const long min_rows = (KIND == kJacobi && kFusedMinRows > 2) ? 2 : kFusedMinRows;
     if (rows < min_rows) rows = min_rows;
   }
-  if (rows > nrows) rows = nrows;
+  if (rows > nrows1) rows = nrows1;
   rows = (rows + 1) & ~1L;
   a.rows_per_chunk = (int)rows;
-  a.n_row_chunks = (int)((nrows + rows - 1) / rows);
+  a.n_row_chunks1 = (int)((nrows1 + rows - 1) / rows);
+  a.n_row_chunks = a.n_row_chunks1 + (int)((nrows2 + rows - 1) / rows);
   // equal shares where whole column groups would leave the XCDs more than MGCMT_FUSED_XCD_IMBALANCE % apart — on levels up
   // to 8192 columns; the 16384^2 level keeps its column bands (measured 6 % faster there)
 #ifndef MGCMT_FUSED_XCD_IMBALANCE

@@ -40,11 +40,13 @@ int fused_max_recompute(const KOp& op, int multicolour, int nsweep) {
 // mode & 8: vout is not written (mode 2 only); npre: pre-smoothing sweeps recomputed before the correction (mode 1).
 void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
                   double omega, int multicolour, int nsweep, int mode, int npre, long row_lo, long row_hi, long last_row, int k,
-                  long rows_override, long out_lo, long out_hi) {
+                  long rows_override, long out_lo, long out_hi, long out_lo2, long out_hi2) {
   fused::FusedArgs a{};
   a.rows_override = (int)rows_override;
   a.out_lo = (int)out_lo;
   a.out_hi = (int)(out_hi < 0 ? g.nr : out_hi);
+  a.out_lo2 = (int)out_lo2;
+  a.out_hi2 = (int)out_hi2;
   a.vin = vin.p;
   a.f = f.p;
   a.vout = vout.p;

@@ -95,10 +95,9 @@ int fused_max_sweeps(const KOp& op, int multicolour);
 int fused_max_recompute(const KOp& op, int multicolour, int nsweep);
 // rows_override: rows per wave chunk (0 = automatic); [out_lo, out_hi): the local rows this launch produces (even
 // bounds; the whole strip is 0 .. g.nr) — a sharded pass runs its boundary rows first so that their exchange overlaps
-// the interior launch
 void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
                   double omega, int multicolour, int nsweep, int mode, int npre, long row_lo, long row_hi, long last_row, int k,
-                  long rows_override = 0, long out_lo = 0, long out_hi = -1);
+                  long rows_override = 0, long out_lo = 0, long out_hi = -1, long out_lo2 = 0, long out_hi2 = 0);
 
 // vector algebra; scalar results / inputs live in device memory so nothing syncs with the host
 void launch_fill(hipStream_t s, double* p, long n, double value);

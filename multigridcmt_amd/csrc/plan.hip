@@ -259,7 +259,7 @@ namespace {
 namespace mgcmt {
 // one fused pass V -> T (then swapped) on a level the fused kernels cover
 int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, hipStream_t s, int npre, long out_lo,
-               long out_hi, bool swap) {
+               long out_hi, bool swap, long out_lo2, long out_hi2) {
   Level& L = p->levels[l];
   KVec coarse{nullptr, 0};
   long cnc = 0;
@@ -273,7 +273,7 @@ int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mod
   const long row_hi = L.r0 + L.nr == L.gr ? L.nr : L.nr + hx;
   launch_fused(s, p->kgrid(l), L.dA.k, p->kvec(l, MGCMT_SLOT_V), p->kvec(l, MGCMT_SLOT_F), p->kvec(l, MGCMT_SLOT_T), coarse, cnc,
                p->d_shifts, omega, kind == MGCMT_GS_MC ? 1 : 0, nsweep, mode, npre, row_lo, row_hi, L.gr - 1 - L.r0, k, p->fused_rows,
-               out_lo, out_hi);
+               out_lo, out_hi, out_lo2, out_hi2);
   if (swap && !(mode & 8)) std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);  // a no-store pass leaves V as it was
   return MGCMT_OK;
 }

@@ -130,7 +130,7 @@ int exchanged_rows(const mgcmt_plan* p, int l);
 // one fused pass V -> T (then swapped); [out_lo, out_hi) = the rows produced (default: the whole strip), swap = false
 // leaves the buffer roles alone (the caller issues the other row ranges of the same pass and swaps once)
 int fused_pass(mgcmt_plan* p, int l, int kind, int nsweep, double omega, int mode, int k, hipStream_t s, int npre = 0,
-               long out_lo = 0, long out_hi = -1, bool swap = true);
+               long out_lo = 0, long out_hi = -1, bool swap = true, long out_lo2 = 0, long out_hi2 = 0);
 void comm_release(mgcmt_plan* p);  // sharded.hip: frees p->comm
 // transfer.hip: a whole vector between caller memory and the device through the pinned ring; completed on return
 int transfer(int device, bool upload, void* dev, void* host, size_t bytes, hipStream_t stream);

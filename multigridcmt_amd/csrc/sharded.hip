@@ -253,8 +253,10 @@ int strip_pass(mgcmt_plan* p, int l, int kind, int n, double omega, int mode, in
     return run_msgs(p, msgs, s);
   }
   const long lo = up ? B : 0, hi = down ? L.nr - B : L.nr;
-  if (up) MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, 0, B, false));
-  if (down) MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, L.nr - B, L.nr, false));
+  // both edges in ONE launch (two row ranges): these launches are pure march latency, 11 - 15 us each
+  if (up && down) MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, 0, B, false, L.nr - B, L.nr));
+  else if (up) MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, 0, B, false));
+  else if (down) MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, L.nr - B, L.nr, false));
   // the messages name the buffer the pass writes: V' lives in slot T until the roles are swapped below
   if (stores_v) {
     std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
@@ -357,8 +359,19 @@ static int comm_common(mgcmt_plan* p, int rank, int nranks, ShardComm** out) {
   c->rank = rank;
   c->nranks = nranks;
   p->comm = c;
-  // non-blocking: work on it must not serialise with the legacy default stream the cycle may be enqueued on
-  hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+  // non-blocking: work on it must not serialise with the legacy default stream the cycle may be enqueued on.  HIGH
+  // priority: a priority stream gets a hardware queue of its own class — an ordinary stream can land on the hardware
+  // queue the cycle's stream uses (HIP deals a few queues round-robin), and two streams on one queue run in order: the
+  // rocprofv3 trace of round 3's first emulated-rank run shows every exchange kernel on the interior launch's queue and
+  // the 500 us interior launch starting only after it (profiles/r03_rank_share_timeline_before.txt) — and the small
+  // exchange kernel is dispatched at once even while the interior launch fills the chip.
+  int prio_low = 0, prio_high = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+  hipError_t e = hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_high);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+  }
   if (e == hipSuccess) e = hipEventCreate(&c->ev_boundary);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_red, sizeof(double) * 2 * kMaxVec);

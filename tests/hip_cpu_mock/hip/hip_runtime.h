@@ -138,6 +138,8 @@ enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureMode
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)1; return hipSuccess; }
 enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)1; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (hipStream_t)1; return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorInvalidValue; }
 inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorInvalidValue; }
