@@ -108,8 +108,9 @@ struct ShardComm {
   mgcmt_allreduce_fn allreduce = nullptr;
   void* user = nullptr;
   hipStream_t comm_stream = nullptr;  // exchanges of boundary rows run here, beside the interior launch
-  hipEvent_t ev_boundary = nullptr, ev_done = nullptr;
-  bool pending = false;   // an exchange is in flight on comm_stream: the next pass waits for ev_done
+  hipEvent_t ev_boundary = nullptr, ev_done = nullptr, ev_edges = nullptr;
+  bool pending = false;   // an exchange is in flight on comm_stream (ev_done follows it): whatever reads halo rows next waits for it
+  bool edges_pending = false;  // a pass's edge rows are being produced on comm_stream (ev_edges follows them): whatever reads them next waits
   bool overlap = true;    // RCCL transport only
   int split = 1;          // boundary rows first (both transports): 1 on strips of >= 2^22 points, 2 always (tests), 0 never
   bool self_ring = false; // one-rank self-test: the rank is its own neighbour above and below in every exchange
@@ -125,6 +126,7 @@ void comm_release(mgcmt_plan* p) {
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->ev_boundary) (void)hipEventDestroy(c->ev_boundary);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->ev_edges) (void)hipEventDestroy(c->ev_edges);
   if (c->d_red) (void)hipFree(c->d_red);
   delete c;
   p->comm = nullptr;
@@ -138,7 +140,9 @@ constexpr int kRing = 0x100;       // mgcmt_halo_exchange: treat a ONE-rank chai
 // Rows of a strip's edge produced first by a split pass: what the neighbour's next pass reads of V (the level's
 // exchanged rows) and, restricted, of the coarse right-hand side (twice the coarse level's exchanged rows).
 long boundary_rows(const mgcmt_plan* p, int l, bool sends_f) {
-  long b = exchanged_rows(p, l);
+  // (+ 2: the interior launch — everything but these rows — then reads no halo row at all, whatever the pass fuses: it
+  // can run before the previous exchange has arrived)
+  long b = exchanged_rows(p, l) + 2;
   if (sends_f && 2L * exchanged_rows(p, l + 1) > b) b = 2L * exchanged_rows(p, l + 1);
   return (b + 1) & ~1L;
 }
@@ -217,12 +221,16 @@ int run_msgs(mgcmt_plan* p, const std::vector<Msg>& msgs, hipStream_t s) {
   return MGCMT_OK;
 }
 
-// the main stream waits for an exchange still running beside it
+// the main stream waits for what still runs beside it: an exchange, a pass's edge rows
 int join_exchange(mgcmt_plan* p, hipStream_t s) {
   ShardComm* c = p->comm;
   if (c->pending) {
     MG_HIP(hipStreamWaitEvent(s, c->ev_done, 0));
     c->pending = false;
+  }
+  if (c->edges_pending) {
+    MG_HIP(hipStreamWaitEvent(s, c->ev_edges, 0));
+    c->edges_pending = false;
   }
   return MGCMT_OK;
 }
@@ -235,7 +243,6 @@ int strip_pass(mgcmt_plan* p, int l, int kind, int n, double omega, int mode, in
                bool exchange_v = true) {
   ShardComm* c = p->comm;
   Level& L = p->levels[l];
-  MG_TRY(join_exchange(p, s));
   const bool stores_v = !(mode & 8) && exchange_v;
   const bool sends_f = (mode & 3) == 2 && coarse_is_strip;
   const bool ring = c->self_ring;
@@ -247,6 +254,7 @@ int strip_pass(mgcmt_plan* p, int l, int kind, int n, double omega, int mode, in
   const bool split = c->split && big && (stores_v || sends_f) && (up || down) && L.nr >= 4 * B;
   std::vector<Msg> msgs;
   if (!split) {
+    MG_TRY(join_exchange(p, s));
     MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre));
     if (stores_v) MG_TRY(halo_msgs(p, l, MGCMT_SLOT_V, ring, k, &msgs));
     if (sends_f) MG_TRY(halo_msgs(p, l + 1, MGCMT_SLOT_F, ring, k, &msgs));
@@ -254,26 +262,45 @@ int strip_pass(mgcmt_plan* p, int l, int kind, int n, double omega, int mode, in
   }
   const long lo = up ? B : 0, hi = down ? L.nr - B : L.nr;
   // both edges in ONE launch (two row ranges): these launches are pure march latency, 11 - 15 us each
-  if (up && down) MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, 0, B, false, L.nr - B, L.nr));
-  else if (up) MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, 0, B, false));
-  else if (down) MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, L.nr - B, L.nr, false));
-  // the messages name the buffer the pass writes: V' lives in slot T until the roles are swapped below
-  if (stores_v) {
-    std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
-    const int rc = halo_msgs(p, l, MGCMT_SLOT_V, ring, k, &msgs);
-    std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
-    MG_TRY(rc);
-  }
-  if (sends_f) MG_TRY(halo_msgs(p, l + 1, MGCMT_SLOT_F, ring, k, &msgs));
+  auto edges = [&](hipStream_t es) {
+    if (up && down) return fused_pass(p, l, kind, n, omega, mode, k, es, npre, 0, B, false, L.nr - B, L.nr);
+    if (up) return fused_pass(p, l, kind, n, omega, mode, k, es, npre, 0, B, false);
+    return fused_pass(p, l, kind, n, omega, mode, k, es, npre, L.nr - B, L.nr, false);
+  };
+  // the messages name the buffer the pass writes: V' lives in slot T until the roles are swapped (by the interior launch)
+  auto messages = [&]() {
+    if (stores_v) {
+      std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
+      const int rc = halo_msgs(p, l, MGCMT_SLOT_V, ring, k, &msgs);
+      std::swap(L.base[MGCMT_SLOT_V], L.base[MGCMT_SLOT_T]);
+      MG_TRY(rc);
+    }
+    if (sends_f) MG_TRY(halo_msgs(p, l + 1, MGCMT_SLOT_F, ring, k, &msgs));
+    return (int)MGCMT_OK;
+  };
   if (c->nccl && c->overlap) {
-    MG_HIP(hipEventRecord(c->ev_boundary, s));
+    // Two lanes.  Main stream: the interior launches, back to back — an interior launch reads no halo row (its rows
+    // lie boundary_rows inside the strip), so it waits for the previous pass's EDGE rows only, never for an exchange.
+    // Exchange stream (high priority): edge rows of this pass — they need the previous pass complete (event on the main
+    // stream) and the previous exchange (stream order) —, then their exchange.  What an exchange costs beyond its
+    // interior launch (it runs starved of bandwidth beside it and ends some 15 us after it, the trace of round 3 shows)
+    // then delays the next pass's edge launch, which runs beside the next interior launch, instead of the whole pass.
+    MG_HIP(hipEventRecord(c->ev_boundary, s));                       // everything before this pass, on the main stream
+    if (c->edges_pending) MG_HIP(hipStreamWaitEvent(s, c->ev_edges, 0));  // interior <- the previous pass's edge rows
     MG_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
+    MG_TRY(edges(c->comm_stream));
+    MG_HIP(hipEventRecord(c->ev_edges, c->comm_stream));
+    c->edges_pending = true;
+    MG_TRY(messages());
     MG_TRY(run_msgs(p, msgs, c->comm_stream));
     MG_HIP(hipEventRecord(c->ev_done, c->comm_stream));
     c->pending = true;
     MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, lo, hi, true));
     return MGCMT_OK;
   }
+  MG_TRY(join_exchange(p, s));
+  MG_TRY(edges(s));
+  MG_TRY(messages());
   MG_TRY(fused_pass(p, l, kind, n, omega, mode, k, s, npre, lo, hi, true));
   return run_msgs(p, msgs, s);
 }
@@ -374,6 +401,7 @@ static int comm_common(mgcmt_plan* p, int rank, int nranks, ShardComm** out) {
   }
   if (e == hipSuccess) e = hipEventCreate(&c->ev_boundary);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_edges);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_red, sizeof(double) * 2 * kMaxVec);
   if (e != hipSuccess) {
     comm_release(p);
