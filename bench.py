@@ -260,7 +260,16 @@ def main(argv=None):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 or args.force_sharded:
         from multigridcmt_amd import dist_bench
-        return dist_bench.run(args)
+        cpu = None
+        if not args.no_cpu_baseline:
+            def cpu():
+                try:
+                    from oracle import structured
+                    return structured.time_cpu_baseline(args.smoother, args.nu, args.lowest, args.cpu_seconds, grid=min(args.grid, 8192),
+                                                        workload_grid=args.grid)
+                except Exception as e:                         # oracle not built on this box: report, do not fail the bench
+                    return {"value": None, "unit": "MLUPS", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
+        return dist_bench.run(args, cpu_baseline=cpu)
     from multigridcmt_amd import _lib
     from multigridcmt_amd.operators import laplacian_operator
     from multigridcmt_amd.plan import Plan
@@ -383,6 +392,32 @@ def main(argv=None):
             lx.close()
         except Exception as e:
             out["cycle_gauss_seidel_lexicographic"] = {"value": None, "error": str(e)}
+    if not args.no_extras:
+        # 1-D cycles (the reference's own problems are 1-D: 1DPotMatrixVcycle.py:68-75, RQMin.py, the UnitTests): the fused
+        # 1-D passes (csrc/kernels_fused1d.hip) at n = 2^24, V(2,2) and the reference's own V(4,4)
+        try:
+            n1 = 1 << 24
+            p1 = Plan(laplacian_operator(n1, "1d") * (-1.0 / np.pi ** 2), args.lowest, nvec=1, device=0)
+            p1.set_shifts([0.0])
+            p1.upload(0, _lib.SLOT_F, 0, f[:n1])
+            rec = {"workload": "1D Laplacian n = 2^24 fp64, lowest_level %d, 1xMI355X" % args.lowest}
+            for name_, (k_, om_) in (("wjacobi", kinds["wjacobi"]), ("redblack", kinds["rb"])):
+                for nu_ in (2, 4):
+                    p1.fill(0, _lib.SLOT_V, 0, 0.0)
+                    t = time_cycles(p1, 20, 3, lambda: p1.vcycle(nu_, nu_, k_, omega=om_, k=1, nu_coarse=nu_))
+                    rec["V%d%d_%s_ms_per_step" % (nu_, nu_, name_)] = t / 20 * 1e3
+            # compulsory bytes of the V(2,2) cycle: 18 + 26 B per point on levels of >= 2^22 points, 26 + 26 below
+            cyc1 = sum((n1 >> l) * ((18.0 + 26.0) if (n1 >> l) >= (1 << 22) else 52.0) for l in range(p1.num_levels - 1) if (n1 >> l) >= 256)
+            rec["V22_compulsory_bytes"] = cyc1
+            rec["V22_wjacobi_compulsory_frac"] = cyc1 / (rec["V22_wjacobi_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            p1.fill(0, _lib.SLOT_V, 0, 0.0)
+            p1.set_option(_lib.OPT_FUSED, 0)
+            t = time_cycles(p1, 5, 2, lambda: p1.vcycle(2, 2, _lib.WJACOBI, omega=2.0 / 3.0, k=1, nu_coarse=2))
+            rec["V22_wjacobi_one_launch_per_operation_ms_per_step"] = t / 5 * 1e3
+            out["cycle_1d"] = rec
+            p1.close()
+        except Exception as e:
+            out["cycle_1d"] = {"value": None, "error": str(e)}
     if not args.no_extras and g == 16384:
         # BASELINE config 4's workload (32768^2, V(2,2) red-black) on this ONE GPU: the base of the strong-scaling
         # curve `bench.py --gpus N` continues.  Right-hand side: the 16384^2 random field interpolated on the device.

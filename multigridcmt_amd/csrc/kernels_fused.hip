@@ -13,6 +13,7 @@ constexpr long kFusedMinCols = MGCMT_FUSED_MIN_COLS;
 // separable operators of two or three Kronecker terms (Laplacian plus potential).  Narrow levels run too (one partly filled wave per
 // chunk): a fused pass there replaces four to nine tiny launches, which is what small levels cost.
 bool fused_supported(const KGrid& g, const KOp& op) {
+  if (!g.coarsen_rows) return fused1d_supported(g, op);
   return g.coarsen_rows && g.nr >= 4 && g.nc >= kFusedMinCols && (g.nc & 1) == 0 && (g.nr & 1) == 0 && (op.five_point || op.five_diag || op.nine_const || op.nine_var || op.nterms == 2 || op.nterms == 3);
 }
 
@@ -20,8 +21,7 @@ bool fused_supported(const KGrid& g, const KOp& op) {
 // rows above the chunk — strips (sharded levels) therefore exchange ten halo rows on 9-point levels (exchanged_rows,
 // plan.hip) and fuse two sweeps like the single plan (they fused one while a strip had eight halo rows).
 int fused_max_sweeps(const KOp& op, int multicolour) {
-  (void)op;
-  (void)multicolour;
+  if (op.one_d) return fused1d_max_sweeps(multicolour);  // (no row pipeline in 1-D: the reference's default nu = 4 is one pass)
   return 2;
 }
 
@@ -29,6 +29,7 @@ int fused_max_sweeps(const KOp& op, int multicolour) {
 // correction (0: none): all stages plus the correction must fit the window overlap (16 columns at most) and
 // the exchanged halo rows of a strip
 int fused_max_recompute(const KOp& op, int multicolour, int nsweep) {
+  if (op.one_d) return fused1d_max_recompute(multicolour, nsweep);
   if (!op.five_point && !op.five_diag && multicolour) return 0;  // four-colour sweeps: four stages each
   const int per_sweep = multicolour ? 2 : 1;
   int n = (8 - per_sweep * nsweep) / per_sweep;
@@ -41,6 +42,7 @@ int fused_max_recompute(const KOp& op, int multicolour, int nsweep) {
 void launch_fused(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
                   double omega, int multicolour, int nsweep, int mode, int npre, long row_lo, long row_hi, long last_row, int k,
                   long rows_override, long out_lo, long out_hi, long out_lo2, long out_hi2) {
+  if (op.one_d) return launch_fused1d(s, g, op, vin, f, vout, coarse, coarse_nc, shifts, omega, multicolour, nsweep, mode, npre, k);
   fused::FusedArgs a{};
   a.rows_override = (int)rows_override;
   a.out_lo = (int)out_lo;

@@ -40,6 +40,11 @@ struct KOp {
   int five_diag, ndiag;
   const double* dX[2];
   const double* dY[2];
+  // 1-D levels: all terms folded into ONE tridiagonal  T = sum_m x_m Y_m  (X_m is 1 x 1): tri = [lower | diag | upper], n
+  // numbers each; tri_const: Toeplitz except for its last diagonal entry (the Laplacian and its Galerkin coarsenings)
+  int one_d, tri_const;
+  const double* tri;
+  double t_lo, t_di, t_up, t_last;
 };
 
 // A batch of vectors on one level: interior pointer of vector 0, elements between vectors.
@@ -91,6 +96,12 @@ void launch_lex_band(hipStream_t s, KGrid g, KOp op, KVec v, KVec f, const doubl
 // residual+restrict last (coarse = right-hand side); mode & 4: vin is zero; mode & 8: vout is not written (mode 2);
 // npre: pre-smoothing sweeps recomputed in front of the correction (mode 1)
 bool fused_supported(const KGrid& g, const KOp& op);
+// the 1-D form (kernels_fused1d.hip): a wave takes a window of 128 points through every stage in registers
+bool fused1d_supported(const KGrid& g, const KOp& op);
+int fused1d_max_sweeps(int multicolour);
+int fused1d_max_recompute(int multicolour, int nsweep);
+void launch_fused1d(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout, KVec coarse, long coarse_nc, const double* shifts,
+                    double omega, int multicolour, int nsweep, int mode, int npre, int k);
 int fused_max_sweeps(const KOp& op, int multicolour);
 int fused_max_recompute(const KOp& op, int multicolour, int nsweep);
 // rows_override: rows per wave chunk (0 = automatic); [out_lo, out_hi): the local rows this launch produces (even

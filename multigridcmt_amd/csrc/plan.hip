@@ -87,6 +87,33 @@ int upload_op(const HostOp& h, const Level& L, int dim, DevOp* d) {
     k.X[m] = dx + L.halo;
     k.Y[m] = dy;
   }
+  if (dim == 1 && h.nterms > 0) {
+    // 1-D: X_m is 1 x 1, so the operator is ONE tridiagonal, sum_m x_m Y_m — folded here for the fused 1-D passes
+    const int64_t n = L.gc;
+    std::vector<double> t(3 * n, 0.0);
+    for (int m = 0; m < h.nterms; ++m) {
+      const double x = h.X[m].di(0);
+      for (int64_t i = 0; i < 3 * n; ++i) t[i] += x * h.Y[m].a[i];
+    }
+    double* dt = nullptr;
+    MG_HIP(hipMalloc((void**)&dt, t.size() * sizeof(double)));
+    d->owned.push_back(dt);
+    MG_HIP(hipMemcpy(dt, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    k.one_d = 1;
+    k.tri = dt;
+    bool constant = n >= 3;
+    for (int64_t i = 0; constant && i < n; ++i) {
+      if (i > 0 && t[i] != t[1]) constant = false;                          // lower (entry 0 is outside the matrix)
+      if (i + 1 < n && (t[n + i] != t[n] || t[2 * n + i] != t[2 * n])) constant = false;  // diagonal but the last, upper (the last entry is outside)
+    }
+    if (constant) {
+      k.tri_const = 1;
+      k.t_lo = t[1];
+      k.t_di = t[n];
+      k.t_up = t[2 * n];
+      k.t_last = t[2 * n - 1];
+    }
+  }
   // constant-coefficient 5-point (2-D) / 3-point (1-D) detection: every factor Toeplitz and the
   // corner coefficients zero -> the kernels take three scalars instead of the factor arrays
   auto toeplitz = [](const Tri& t, double* lo, double* di, double* up) {

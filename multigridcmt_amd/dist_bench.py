@@ -106,8 +106,8 @@ def time_rank_share(g, nu, lowest, smoother, erank, of, steps=10, warmup=3, devi
         sp.close()
 
 
-def run(args, backend="nccl", on_gpu=True):
-    """backend / on_gpu exist for the CPU rehearsal of this very function (tests/test_distributed.py: gloo, host memory,
+def run(args, backend="nccl", on_gpu=True, cpu_baseline=None):
+    """cpu_baseline: a callable returning bench.py's `cpu_baseline` record (called on rank 0, untimed).  backend / on_gpu exist for the CPU rehearsal of this very function (tests/test_distributed.py: gloo, host memory,
     emulated kernels); bench.py always calls it with the defaults."""
     import torch
     import torch.distributed as dist
@@ -248,13 +248,8 @@ def run(args, backend="nccl", on_gpu=True):
                                             "timed; the halo rows hold the rank's own rows, so residuals and checksums are NOT the job's"
                                             % (sp.emulate[0], sp.emulate[1])}
             out["ms_per_rank_share"] = out["ms_per_step"]
-        if not getattr(args, "no_cpu_baseline", True):
-            try:
-                from oracle import structured
-                out["cpu_baseline"] = structured.time_cpu_baseline(args.smoother, args.nu, args.lowest, getattr(args, "cpu_seconds", 12.0),
-                                                                   grid=min(g, 8192), workload_grid=g)
-            except Exception as e:                                # oracle not built on this box: report, do not fail
-                out["cpu_baseline"] = {"value": None, "unit": "MLUPS", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
+        if cpu_baseline is not None:                               # bench.py owns that leg (the CPU checker is not importable from this package)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     sp.close()
     dist.destroy_process_group()
