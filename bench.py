@@ -45,6 +45,7 @@ def parse(argv=None):
     ap.add_argument("--lowest", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline cycle and its roofline record")
+    ap.add_argument("--skip", default="", help="comma-separated extra legs to leave out: other, mehrstellen, lex, 1d, scaling, configs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
     ap.add_argument("--switch-grid", type=int, default=None, help="multi-GPU: grid below which every rank runs the whole problem")
@@ -275,6 +276,11 @@ def main(argv=None):
     from multigridcmt_amd.plan import Plan
 
     g = args.grid
+    skipped = set(x for x in args.skip.split(",") if x)
+
+    def leg(name):
+        return not args.no_extras and name not in skipped
+
     kinds = {"wjacobi": (_lib.WJACOBI, 2.0 / 3.0), "rb": (_lib.GS_MC, 1.0)}
     kind, omega = kinds[args.smoother]
     op = laplacian_operator(g, "2d") * (-1.0 / np.pi ** 2)
@@ -321,7 +327,7 @@ def main(argv=None):
     out["roofline"]["measured_ceilings_GBs"] = {
         name: n * bpp / (plan.bandwidth_probe(0, k_, 1024, 5) * 1e-3) / 1e9
         for k_, name, bpp in ((0, "copy", 16), (1, "triad", 24), (2, "read", 8))}
-    if not args.no_extras:
+    if leg('other'):
         other = "rb" if args.smoother == "wjacobi" else "wjacobi"
         okind, oomega = kinds[other]
         # north_star's target kernel (the red-black fine-grid sweep) when the headline smoother is weighted Jacobi,
@@ -352,7 +358,7 @@ def main(argv=None):
         history.append(float(np.sqrt(plan.dot(0, T, T)) / f_norm))
     out["residual_reduction_per_cycle"] = history
     plan.close()
-    if not args.no_extras:
+    if leg('mehrstellen'):
         # SURVEY par. 8(f)3: the same cycle on the fourth-order compact 9-point (Mehrstellen) fine-grid operator
         try:
             from multigridcmt_amd.operators import mehrstellen_operator
@@ -369,7 +375,7 @@ def main(argv=None):
             m9.close()
         except Exception as e:
             out["cycle_mehrstellen"] = {"value": None, "error": str(e)}
-    if not args.no_extras:
+    if leg('lex'):
         # the reference's DEFAULT smoother — lexicographic Gauss-Seidel (MGCMTSolver.py:210-227; `smoother=None` ->
         # `self.gseidel`, :291) — at BASELINE config 2's grid: V(2,2), and V(2,2) on top / V(4,4) below (:320), as a
         # pipeline of waves with the sweeps of a smoothing step chained in one launch, against the one-workgroup kernel
@@ -392,7 +398,7 @@ def main(argv=None):
             lx.close()
         except Exception as e:
             out["cycle_gauss_seidel_lexicographic"] = {"value": None, "error": str(e)}
-    if not args.no_extras:
+    if leg('1d'):
         # 1-D cycles (the reference's own problems are 1-D: 1DPotMatrixVcycle.py:68-75, RQMin.py, the UnitTests): the fused
         # 1-D passes (csrc/kernels_fused1d.hip) at n = 2^24, V(2,2) and the reference's own V(4,4)
         try:
@@ -418,7 +424,7 @@ def main(argv=None):
             p1.close()
         except Exception as e:
             out["cycle_1d"] = {"value": None, "error": str(e)}
-    if not args.no_extras and g == 16384:
+    if leg('scaling') and g == 16384:
         # BASELINE config 4's workload (32768^2, V(2,2) red-black) on this ONE GPU: the base of the strong-scaling
         # curve `bench.py --gpus N` continues.  Right-hand side: the 16384^2 random field interpolated on the device.
         try:
@@ -459,7 +465,7 @@ def main(argv=None):
                 out["strong_scaling_base"]["rank_share_of_8"] = {"value": None, "error": str(e)}
         except Exception as e:                                  # e.g. a smaller-memory device
             out["strong_scaling_base"] = {"value": None, "error": str(e)}
-    if not args.no_extras and g == 16384:
+    if leg('configs') and g == 16384:
         # BASELINE configs 2 and 5 in the same line (their own bench commands: `--config 1`, scripts/bench_config5.py)
         try:
             g2 = 4096

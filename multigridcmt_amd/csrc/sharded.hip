@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "plan_internal.h"
@@ -250,7 +251,12 @@ int strip_pass(mgcmt_plan* p, int l, int kind, int n, double omega, int mode, in
   const long B = boundary_rows(p, l, sends_f);
   // two extra launches cost about 10 us on the stream; the exchange they free from the critical path is worth more than
   // that only on strips whose interior launch is long enough to hide it (c->split == 2: always, for tests)
-  const bool big = c->split == 2 || (long)L.nr * L.gc * k >= (1L << 22);
+  static const int split_min_log2 = [] {
+    const char* e = getenv("MGCMT_COMM_SPLIT_MIN_LOG2");  // tuning: strips of at least 2^this points take the split schedule
+    const int v = e ? atoi(e) : 22;
+    return v < 10 || v > 40 ? 22 : v;
+  }();
+  const bool big = c->split == 2 || (long)L.nr * L.gc * k >= (1L << split_min_log2);
   const bool split = c->split && big && (stores_v || sends_f) && (up || down) && L.nr >= 4 * B;
   std::vector<Msg> msgs;
   if (!split) {
@@ -386,19 +392,22 @@ static int comm_common(mgcmt_plan* p, int rank, int nranks, ShardComm** out) {
   c->rank = rank;
   c->nranks = nranks;
   p->comm = c;
-  // non-blocking: work on it must not serialise with the legacy default stream the cycle may be enqueued on.  HIGH
-  // priority: a priority stream gets a hardware queue of its own class — an ordinary stream can land on the hardware
-  // queue the cycle's stream uses (HIP deals a few queues round-robin), and two streams on one queue run in order: the
-  // rocprofv3 trace of round 3's first emulated-rank run shows every exchange kernel on the interior launch's queue and
-  // the 500 us interior launch starting only after it (profiles/r03_rank_share_timeline_before.txt) — and the small
-  // exchange kernel is dispatched at once even while the interior launch fills the chip.
-  int prio_low = 0, prio_high = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-  hipError_t e = hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_high);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+  // non-blocking: work on it must not serialise with the legacy default stream the cycle may be enqueued on.
+  // An ORDINARY stream.  A high-priority one (its own class of hardware queue) was tried in round 3 and measured: equal to
+  // an ordinary stream in a fresh process (2.22 ms per emulated rank share of the 32768^2 cycle either way) — but created
+  // AFTER the eight DMA lane streams of csrc/transfer.hip exist (any process that uploaded >= 16 MiB first, bench.py's
+  // one-GPU line for one) every small kernel of the process then takes ~55 us and the share 3.9 ms: the hardware queues are
+  // oversubscribed and time-sliced (rocprofv3 trace: profiles/r03_rank_share_priority_stream_oversubscribed.txt).
+  // MGCMT_COMM_PRIORITY=1 selects the priority stream (A/B measurements).
+  const char* pe = getenv("MGCMT_COMM_PRIORITY");
+  hipError_t e = hipErrorUnknown;
+  if (pe && pe[0] == '1') {
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    e = hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_high);
+    if (e != hipSuccess) (void)hipGetLastError();
   }
+  if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_boundary);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_edges);
