@@ -171,6 +171,15 @@ int mgcmt_rayleigh_residual(mgcmt_plan* plan, int level, int slot, int k, double
  * differ from x and w.  Synchronises. */
 int mgcmt_ritz_pair(mgcmt_plan* plan, int level, int x_slot, int x_vec, int w_slot, int w_vec, int scratch_slot, int scratch_vec,
                     double* out5, void* stream);
+/* rqmin (MGCMTSolver.py:17-57): nu steps of Rayleigh-quotient minimisation on `level` for the plan's pair (A, M) (M = I
+ * without a mass operator), entirely on the device — per step TWO passes over the data (p = -g + beta p_old formed on the
+ * fly, A and M applied to x and p in registers, the eight inner products of the 2 x 2 pencil of :33-46; then x + delta p, its
+ * gradient g = 2 (A x - rho M x) and the next step's inner products), the pencil solved in closed form by one workgroup,
+ * no host round trip.  vecs[0] of `slot` holds the start vector and receives the result; vecs[1..5] are five more, distinct
+ * vectors of the slot used as work space.  robust != 0: a degenerate pencil ends the minimisation instead of producing
+ * infinities (the repaired variants).  rho_out (may be NULL: nothing synchronises then): the Rayleigh quotient of the
+ * result (:53). */
+int mgcmt_rqmin(mgcmt_plan* plan, int level, int slot, const int* vecs, int nu, int robust, double* rho_out, void* stream);
 /* dst = sum_t coeffs[t] * (slots[t], vecs[t]), 1 <= nterms <= 4; dst may be one of the inputs (the updates
  * x <- x + delta p, MGCMTSolver.py:52, and the residual A x - rho M x, :22-23, in one pass each) */
 int mgcmt_lincomb(mgcmt_plan* plan, int level, int nterms, const double* coeffs, const int* slots, const int* vecs, int dst_slot,

@@ -1,0 +1,489 @@
+// Rayleigh-quotient minimisation (MGCMTSolver.py:17-57) as TWO passes over the data per step and no host round trip.
+//
+// The reference's step:  p <- -g + beta p;  the 2 x 2 pencil on span{x, p} from eight inner products with A x, A p, M x,
+// M p (:33-46);  x <- x + delta p (:50-52);  rho = <x,Ax>/<x,Mx> (:53);  g <- 2 (A x - rho M x) (:55).  Taken literally
+// that is six operator applications, three Gram passes and four vector updates per step with three host round trips
+// (the round-2 form, ~300 B per point and step).  Here:
+//   pass 1  reads x, g, p_old: forms p = -g + beta p_old on the fly (beta is a device scalar), applies A and M to x and p
+//           in registers, accumulates the eight inner products, writes p                                  (32 B per point)
+//   scalars one workgroup: sums the per-block partial sums in a fixed order, solves the 2 x 2 generalised eigenproblem in
+//           closed form, delta = y1/y0 of the smaller eigenvalue's vector; rho of x + delta p from the same eight numbers
+//   pass 2  reads x, p: forms x' = x + delta p on the fly, applies A and M to it, g' = 2 (A x' - rho M x'); writes x', g';
+//           accumulates <x',Ax'>, <x',Mx'> (the rho that is reported, :53) and <g',g'>                     (32 B per point)
+//   scalars rho, beta = <g',Mg'> / <g,Mg> for the next step (:31).  With M != I, <g',Mg'> takes one more application.
+// x and p are ping-ponged between two vectors each: a pass recomputes the combination at the neighbours' points, so it
+// must not overwrite what they still read.
+//
+// 2-D levels with even sizes take the row march of kernels_stencil.hip (a thread owns two adjacent columns and walks down
+// a chunk of rows with the 3 x 4 neighbourhoods of both vectors in registers); 1-D levels and odd shapes a
+// one-thread-per-point form with the same arithmetic.
+#include <cstdint>
+
+#include "mgcmt_internal.h"
+
+namespace mgcmt {
+
+namespace {
+
+// state words (doubles in device memory, one block per plan)
+enum {
+  kS_xAx = 0, kS_xAp, kS_pAx, kS_pAp, kS_xMx, kS_xMp, kS_pMx, kS_pMp,  // pass 1
+  kDelta = 8, kRho, kBeta, kGMGprev, kGMG, kStop, kXAXn, kXMXn, kGG, kRhoLin,
+  kRqStateWords = 32
+};
+
+struct Row4 {
+  double w, a, b, e;  // columns j-1, j, j+1, j+2 (zero outside the grid)
+};
+
+template <int M>
+struct Fac {
+  double yl[M > 0 ? M : 1][2], yd[M > 0 ? M : 1][2], yu[M > 0 ? M : 1][2];
+};
+
+template <int M>
+__device__ __forceinline__ void load_fac(const KOp& op, long j, Fac<M>& f) {
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const double* Y = op.Y[m] + j + c;
+      f.yl[m][c] = Y[0];
+      f.yd[m][c] = Y[op.ldy];
+      f.yu[m][c] = Y[2 * op.ldy];
+    }
+}
+
+// (Op v) at (i, j) and (i, j+1) from the rows above / at / below; M == 0: the identity.  eval_point's expressions.
+template <int M>
+__device__ __forceinline__ void apply2(const KOp& op, const Fac<M>& f, long i, const Row4& n, const Row4& c, const Row4& s, double& ra, double& rb) {
+  if (M == 0) {
+    ra = c.a;
+    rb = c.b;
+    return;
+  }
+  double offa = 0.0, offb = 0.0, da = 0.0, db = 0.0;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const double* X = op.X[m] + i;
+    const double xl = X[0], xd = X[op.ldx], xu = X[2 * op.ldx];
+    {
+      const double rn = f.yl[m][0] * n.w + f.yd[m][0] * n.a + f.yu[m][0] * n.b;
+      const double rc = f.yl[m][0] * c.w + f.yu[m][0] * c.b;
+      const double rs = f.yl[m][0] * s.w + f.yd[m][0] * s.a + f.yu[m][0] * s.b;
+      offa += xl * rn + xd * rc + xu * rs;
+      da += xd * f.yd[m][0];
+    }
+    {
+      const double rn = f.yl[m][1] * n.a + f.yd[m][1] * n.b + f.yu[m][1] * n.e;
+      const double rc = f.yl[m][1] * c.a + f.yu[m][1] * c.e;
+      const double rs = f.yl[m][1] * s.a + f.yd[m][1] * s.b + f.yu[m][1] * s.e;
+      offb += xl * rn + xd * rc + xu * rs;
+      db += xd * f.yd[m][1];
+    }
+  }
+  ra = offa + da * c.a;
+  rb = offb + db * c.b;
+}
+
+constexpr int kRqThreads = 256;
+constexpr int kRqSums = 8;
+
+// per block: nq partial sums into partials[q * nblocks + block] (fixed order: deterministic)
+template <int NQ>
+__device__ __forceinline__ void block_partials(const double* acc, double (*s_part)[kRqThreads / 64], double* __restrict__ partials, int nblocks, int block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double t = acc[q];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
+    if (lane == 0) s_part[q][wave] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NQ) {
+    double t = 0.0;
+    const int nw = blockDim.x >> 6;
+    for (int k = 0; k < nw; ++k) t += s_part[threadIdx.x][k];
+    partials[(long)threadIdx.x * nblocks + block] = t;
+  }
+}
+
+// ---- row march (2-D, even sizes) ------------------------------------------------------------------------------
+
+// v = cu * u + cw * w at columns j-1 .. j+2 of row i (u alone when w == nullptr)
+__device__ __forceinline__ Row4 load4(const double* __restrict__ u, const double* __restrict__ w, double cu, double cw, long i, long nc, long j, long jw,
+                                      long je, bool hw, bool he) {
+  const double2 c = *reinterpret_cast<const double2*>(u + i * nc + j);
+  Row4 r{hw ? u[i * nc + jw] : 0.0, c.x, c.y, he ? u[i * nc + je] : 0.0};
+  if (!w && cu != 1.0) {
+    r.w *= cu;
+    r.a *= cu;
+    r.b *= cu;
+    r.e *= cu;
+  }
+  if (w) {
+    const double2 d = *reinterpret_cast<const double2*>(w + i * nc + j);
+    const double dw = hw ? w[i * nc + jw] : 0.0, de = he ? w[i * nc + je] : 0.0;
+    r.w = cu * r.w + cw * dw;
+    r.a = cu * r.a + cw * d.x;
+    r.b = cu * r.b + cw * d.y;
+    r.e = cu * r.e + cw * de;
+  }
+  return r;
+}
+
+template <int MA, int MM>
+__global__ void __launch_bounds__(kRqThreads) k_rq_pass1(KGrid g, KOp A, KOp Mo, const double* __restrict__ x, const double* __restrict__ gv,
+                                                        const double* __restrict__ pold, double* __restrict__ pnew, const double* __restrict__ state,
+                                                        int init, int rows, double* __restrict__ partials, int nblocks) {
+  __shared__ double s_part[kRqSums][kRqThreads / 64];
+  const long j = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  const long nc = g.nc;
+  const long i0 = (long)blockIdx.y * rows;
+  const long i1 = i0 + rows < g.nr ? i0 + rows : g.nr;
+  double acc[kRqSums];
+#pragma unroll
+  for (int q = 0; q < kRqSums; ++q) acc[q] = 0.0;
+  if (j < nc) {
+    const bool hw = j > 0, he = j + 2 < nc;
+    const long jw = hw ? j - 1 : j, je = he ? j + 2 : j + 1;
+    const double beta = init ? 0.0 : state[kBeta];
+    const double* po = init == 2 ? nullptr : pold;  // the first step takes p = -g (MGCMTSolver.py:29-30): p_old is not read
+    Fac<MA> fa;
+    Fac<MM> fm;
+    load_fac<MA>(A, j, fa);
+    load_fac<MM>(Mo, j, fm);
+    const Row4 zero{0.0, 0.0, 0.0, 0.0};
+    auto loadp = [&](long i) { return init == 1 ? zero : load4(gv, po, -1.0, beta, i, nc, j, jw, je, hw, he); };
+    Row4 xn = load4(x, nullptr, 1.0, 0.0, i0 - 1, nc, j, jw, je, hw, he), xc = load4(x, nullptr, 1.0, 0.0, i0, nc, j, jw, je, hw, he);
+    Row4 pn = loadp(i0 - 1), pc = loadp(i0);
+#pragma unroll 2
+    for (long i = i0; i < i1; ++i) {
+      const Row4 xs = load4(x, nullptr, 1.0, 0.0, i + 1, nc, j, jw, je, hw, he);
+      const Row4 ps = loadp(i + 1);
+      double axa, axb, apa, apb, mxa, mxb, mpa, mpb;
+      apply2<MA>(A, fa, i, xn, xc, xs, axa, axb);
+      apply2<MA>(A, fa, i, pn, pc, ps, apa, apb);
+      apply2<MM>(Mo, fm, i, xn, xc, xs, mxa, mxb);
+      apply2<MM>(Mo, fm, i, pn, pc, ps, mpa, mpb);
+      acc[kS_xAx] += xc.a * axa + xc.b * axb;
+      acc[kS_xAp] += xc.a * apa + xc.b * apb;
+      acc[kS_pAx] += pc.a * axa + pc.b * axb;
+      acc[kS_pAp] += pc.a * apa + pc.b * apb;
+      acc[kS_xMx] += xc.a * mxa + xc.b * mxb;
+      acc[kS_xMp] += xc.a * mpa + xc.b * mpb;
+      acc[kS_pMx] += pc.a * mxa + pc.b * mxb;
+      acc[kS_pMp] += pc.a * mpa + pc.b * mpb;
+      if (init != 1) *reinterpret_cast<double2*>(pnew + i * nc + j) = make_double2(pc.a, pc.b);
+      xn = xc;
+      xc = xs;
+      pn = pc;
+      pc = ps;
+    }
+  }
+  block_partials<kRqSums>(acc, s_part, partials, nblocks, (int)(blockIdx.y * gridDim.x + blockIdx.x));
+}
+
+template <int MA, int MM>
+__global__ void __launch_bounds__(kRqThreads) k_rq_pass2(KGrid g, KOp A, KOp Mo, const double* __restrict__ x, const double* __restrict__ p,
+                                                        double* __restrict__ xnew, double* __restrict__ gout, const double* __restrict__ state, int init,
+                                                        int rows, double* __restrict__ partials, int nblocks) {
+  __shared__ double s_part[3][kRqThreads / 64];
+  const long j = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  const long nc = g.nc;
+  const long i0 = (long)blockIdx.y * rows;
+  const long i1 = i0 + rows < g.nr ? i0 + rows : g.nr;
+  double acc[3] = {0.0, 0.0, 0.0};
+  if (j < nc) {
+    const bool hw = j > 0, he = j + 2 < nc;
+    const long jw = hw ? j - 1 : j, je = he ? j + 2 : j + 1;
+    const double delta = state[kDelta], rho = state[kRhoLin];
+    Fac<MA> fa;
+    Fac<MM> fm;
+    load_fac<MA>(A, j, fa);
+    load_fac<MM>(Mo, j, fm);
+    const double* pp = init == 1 ? nullptr : p;
+    Row4 xn = load4(x, pp, 1.0, delta, i0 - 1, nc, j, jw, je, hw, he), xc = load4(x, pp, 1.0, delta, i0, nc, j, jw, je, hw, he);
+#pragma unroll 2
+    for (long i = i0; i < i1; ++i) {
+      const Row4 xs = load4(x, pp, 1.0, delta, i + 1, nc, j, jw, je, hw, he);
+      double axa, axb, mxa, mxb;
+      apply2<MA>(A, fa, i, xn, xc, xs, axa, axb);
+      apply2<MM>(Mo, fm, i, xn, xc, xs, mxa, mxb);
+      const double ga = 2.0 * (axa - rho * mxa), gb = 2.0 * (axb - rho * mxb);
+      *reinterpret_cast<double2*>(xnew + i * nc + j) = make_double2(xc.a, xc.b);
+      *reinterpret_cast<double2*>(gout + i * nc + j) = make_double2(ga, gb);
+      acc[0] += xc.a * axa + xc.b * axb;
+      acc[1] += xc.a * mxa + xc.b * mxb;
+      acc[2] += ga * ga + gb * gb;
+      xn = xc;
+      xc = xs;
+    }
+  }
+  block_partials<3>(acc, s_part, partials, nblocks, (int)(blockIdx.y * gridDim.x + blockIdx.x));
+}
+
+// ---- one thread per point (1-D levels, odd shapes): the same arithmetic through direct neighbour loads ---------------
+
+// (Op v)(i, j) with v = cu u + cw w (u alone when w == nullptr); identity: v(i, j)
+__device__ __forceinline__ double apply_point(const KOp& op, int identity, const double* __restrict__ u, const double* __restrict__ w, double cu, double cw,
+                                              long nc, long i, long j) {
+  auto val = [&](long off) { return w ? cu * u[off] + cw * w[off] : cu * u[off]; };
+  const long c = i * nc + j;
+  if (identity) return val(c);
+  const bool hw = j > 0, he = j + 1 < nc;
+  const double vc = val(c), n = val(c - nc), s = val(c + nc);
+  const double wv = hw ? val(c - 1) : 0.0, e = he ? val(c + 1) : 0.0;
+  const double nw = hw ? val(c - nc - 1) : 0.0, ne = he ? val(c - nc + 1) : 0.0;
+  const double sw = hw ? val(c + nc - 1) : 0.0, se = he ? val(c + nc + 1) : 0.0;
+  double off = 0.0, diag = 0.0;
+  for (int m = 0; m < op.nterms; ++m) {
+    const double* X = op.X[m] + i;
+    const double* Y = op.Y[m] + j;
+    const double xl = X[0], xd = X[op.ldx], xu = X[2 * op.ldx];
+    const double yl = Y[0], yd = Y[op.ldy], yu = Y[2 * op.ldy];
+    const double rn = yl * nw + yd * n + yu * ne;
+    const double rc = yl * wv + yu * e;
+    const double rs = yl * sw + yd * s + yu * se;
+    off += xl * rn + xd * rc + xu * rs;
+    diag += xd * yd;
+  }
+  return off + diag * vc;
+}
+
+__global__ void __launch_bounds__(kRqThreads) k_rq_pass1_point(KGrid g, KOp A, KOp Mo, int m_identity, const double* __restrict__ x,
+                                                              const double* __restrict__ gv, const double* __restrict__ pold, double* __restrict__ pnew,
+                                                              const double* __restrict__ state, int init, double* __restrict__ partials, int nblocks) {
+  __shared__ double s_part[kRqSums][kRqThreads / 64];
+  const long n = g.nr * g.nc;
+  const double beta = init ? 0.0 : state[kBeta];
+  double acc[kRqSums];
+#pragma unroll
+  for (int q = 0; q < kRqSums; ++q) acc[q] = 0.0;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+    const long i = k / g.nc, j = k - i * g.nc;
+    const double* po = init == 2 ? nullptr : pold;
+    const double xc = x[k], pc = init == 1 ? 0.0 : (po ? -gv[k] + beta * po[k] : -gv[k]);
+    const double ax = apply_point(A, 0, x, nullptr, 1.0, 0.0, g.nc, i, j), mx = apply_point(Mo, m_identity, x, nullptr, 1.0, 0.0, g.nc, i, j);
+    const double ap = init == 1 ? 0.0 : apply_point(A, 0, gv, po, -1.0, beta, g.nc, i, j);
+    const double mp = init == 1 ? 0.0 : apply_point(Mo, m_identity, gv, po, -1.0, beta, g.nc, i, j);
+    acc[kS_xAx] += xc * ax;
+    acc[kS_xAp] += xc * ap;
+    acc[kS_pAx] += pc * ax;
+    acc[kS_pAp] += pc * ap;
+    acc[kS_xMx] += xc * mx;
+    acc[kS_xMp] += xc * mp;
+    acc[kS_pMx] += pc * mx;
+    acc[kS_pMp] += pc * mp;
+    if (init != 1) pnew[k] = pc;
+  }
+  block_partials<kRqSums>(acc, s_part, partials, nblocks, (int)blockIdx.x);
+}
+
+__global__ void __launch_bounds__(kRqThreads) k_rq_pass2_point(KGrid g, KOp A, KOp Mo, int m_identity, const double* __restrict__ x,
+                                                              const double* __restrict__ p, double* __restrict__ xnew, double* __restrict__ gout,
+                                                              const double* __restrict__ state, int init, double* __restrict__ partials, int nblocks) {
+  __shared__ double s_part[3][kRqThreads / 64];
+  const long n = g.nr * g.nc;
+  const double delta = state[kDelta], rho = state[kRhoLin];
+  const double* pp = init == 1 ? nullptr : p;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+    const long i = k / g.nc, j = k - i * g.nc;
+    const double xc = pp ? x[k] + delta * pp[k] : x[k];
+    const double ax = apply_point(A, 0, x, pp, 1.0, delta, g.nc, i, j), mx = apply_point(Mo, m_identity, x, pp, 1.0, delta, g.nc, i, j);
+    const double gg = 2.0 * (ax - rho * mx);
+    xnew[k] = xc;
+    gout[k] = gg;
+    acc[0] += xc * ax;
+    acc[1] += xc * mx;
+    acc[2] += gg * gg;
+  }
+  block_partials<3>(acc, s_part, partials, nblocks, (int)blockIdx.x);
+}
+
+// ---- scalars --------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double reduce_result(const double* __restrict__ partials, int nblocks, double* s_buf) {
+  // one result's per-block partial sums: thread-strided, then a fixed tree (256 threads)
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) acc += partials[i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_buf[wave] = acc;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_buf[w];
+  return t;  // on every thread
+}
+
+// after pass 1: the 2 x 2 pencil R y = lambda RM y (MGCMTSolver.py:33-49), delta = y1 / y0 of the smaller eigenvalue
+// (:49-50), and rho of x + delta p by bilinearity (what pass 2 needs before it has formed x').  init: delta = 0.
+// robust (the repaired variants, solver.py): a degenerate pencil ends the minimisation on this level (delta = 0 from
+// here on) instead of producing infinities.
+__global__ void __launch_bounds__(kRqThreads) k_rq_scalars1(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int init,
+                                                           int robust) {
+  __shared__ double s_buf[kRqThreads / 64];
+  double s[kRqSums];
+  for (int q = 0; q < kRqSums; ++q) s[q] = reduce_result(partials + (long)q * nblocks, nblocks, s_buf);
+  if (threadIdx.x != 0) return;
+  for (int q = 0; q < kRqSums; ++q) state[q] = s[q];
+  const double r00 = s[kS_xAx], r01 = s[kS_xAp], r10 = s[kS_pAx], r11 = s[kS_pAp];
+  const double m00 = s[kS_xMx], m01 = s[kS_xMp], m10 = s[kS_pMx], m11 = s[kS_pMp];
+  if (init == 1) {
+    state[kDelta] = 0.0;
+    state[kRhoLin] = r00 / m00;
+    state[kStop] = 0.0;
+    return;
+  }
+  double delta = 0.0;
+  bool stop = state[kStop] != 0.0;
+  if (!stop && robust) {
+    const double ms01 = 0.5 * (m01 + m10);
+    const double scale = fabs(m00) > 1e-300 ? fabs(m00) : 1e-300;
+    auto fin = [](double v) { return fabs(v) <= 1.7e308; };  // (false for NaN and the infinities)
+    const bool finite = fin(r00) && fin(r01) && fin(r10) && fin(r11) && fin(m00) && fin(ms01) && fin(m11);
+    if (!finite || m11 <= 1e-28 * scale || (m00 * m11 - ms01 * ms01) <= 1e-14 * m00 * m11) stop = true;
+  }
+  if (!stop) {
+    // det(R - l RM) = a l^2 + b l + c; the smaller root (a > 0 for a definite RM), stable form
+    const double a = m00 * m11 - m01 * m10;
+    const double b = -(r00 * m11 + m00 * r11) + (r01 * m10 + m01 * r10);
+    const double c = r00 * r11 - r01 * r10;
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) disc = 0.0;
+    const double q = -0.5 * (b + (b >= 0.0 ? sqrt(disc) : -sqrt(disc)));
+    const double l1 = q / a, l2 = q != 0.0 ? c / q : l1;
+    const double lam = l1 < l2 ? l1 : l2;  // (np.argmin of the two eigenvalues, :49)
+    // eigenvector from the row (p, .): delta = y1 / y0 = -(r10 - l m10) / (r11 - l m11).  That row, not (x, .): its
+    // numerator is p . (A x - l M x), a product with the gradient, where the other row's r00 - l m00 cancels two numbers
+    // of the size of <x, A x> down to rounding noise once x has converged (a 2-point level after one step) — and p may be
+    // of ANY size, so the rows cannot be compared by magnitude.  The row (x, .) only when the pencil leaves no choice.
+    const double n2 = r10 - lam * m10, d2 = r11 - lam * m11;
+    delta = -n2 / d2;
+    if (!(fabs(delta) <= 1.7e308)) delta = -(r00 - lam * m00) / (r01 - lam * m01);
+    if (robust && !(fabs(delta) < 1e300)) {  // y0 = 0: the minimiser is p itself — the reference's ratio is infinite
+      stop = true;
+      delta = 0.0;
+    }
+  }
+  state[kStop] = stop ? 1.0 : 0.0;
+  state[kDelta] = delta;
+  state[kRhoLin] = (r00 + delta * (r01 + r10) + delta * delta * r11) / (m00 + delta * (m01 + m10) + delta * delta * m11);
+}
+
+// after pass 2 (and, with M != I, after <g, M g> has been put into state[kGMG] by a dot product): rho (:53), beta (:31)
+__global__ void __launch_bounds__(kRqThreads) k_rq_scalars2(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int m_identity,
+                                                           int init) {
+  __shared__ double s_buf[kRqThreads / 64];
+  double s[3];
+  for (int q = 0; q < 3; ++q) s[q] = reduce_result(partials + (long)q * nblocks, nblocks, s_buf);
+  if (threadIdx.x != 0) return;
+  state[kXAXn] = s[0];
+  state[kXMXn] = s[1];
+  state[kGG] = s[2];
+  state[kRho] = s[0] / s[1];
+  const double gmg = m_identity ? s[2] : state[kGMG];
+  // the first step takes p = -g (:29-30): beta = 0; afterwards <g,Mg> / <g_old,Mg_old>
+  state[kBeta] = init == 1 ? 0.0 : gmg / state[kGMGprev];
+  state[kGMGprev] = gmg;
+  state[kGMG] = gmg;
+}
+
+// the step after the first real one must use beta = <g1,Mg1>/<g0,Mg0>: scalars2 of the init pair stores <g0,Mg0> and beta
+// = 0 (first step: p = -g); scalars2 of step 1 then finds kGMGprev = <g0,Mg0>.
+__global__ void k_rq_store(double* __restrict__ state, int word, const double* __restrict__ value) { state[word] = value[0]; }
+
+template <int MA>
+void launch_pass1_ma(hipStream_t s, int mm, dim3 grid, dim3 block, KGrid g, const KOp& A, const KOp& Mo, const double* x, const double* gv,
+                     const double* pold, double* pnew, const double* state, int init, int rows, double* partials, int nblocks) {
+  if (mm == 0) hipLaunchKernelGGL((k_rq_pass1<MA, 0>), grid, block, 0, s, g, A, Mo, x, gv, pold, pnew, state, init, rows, partials, nblocks);
+  else hipLaunchKernelGGL((k_rq_pass1<MA, 1>), grid, block, 0, s, g, A, Mo, x, gv, pold, pnew, state, init, rows, partials, nblocks);
+}
+
+template <int MA>
+void launch_pass2_ma(hipStream_t s, int mm, dim3 grid, dim3 block, KGrid g, const KOp& A, const KOp& Mo, const double* x, const double* p,
+                     double* xnew, double* gout, const double* state, int init, int rows, double* partials, int nblocks) {
+  if (mm == 0) hipLaunchKernelGGL((k_rq_pass2<MA, 0>), grid, block, 0, s, g, A, Mo, x, p, xnew, gout, state, init, rows, partials, nblocks);
+  else hipLaunchKernelGGL((k_rq_pass2<MA, 1>), grid, block, 0, s, g, A, Mo, x, p, xnew, gout, state, init, rows, partials, nblocks);
+}
+
+bool march_ok(const KGrid& g, const KOp& A, const KOp& Mo, int m_identity, const double* a, const double* b, const double* c, const double* d,
+              const double* e) {
+  const uintptr_t all = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e;
+  return g.coarsen_rows && g.nr >= 2 && g.nc >= 2 && (g.nc & 1) == 0 && (all & 15) == 0 && A.nterms >= 1 && A.nterms <= 4 &&
+         (m_identity || Mo.nterms == 1);
+}
+
+}  // namespace
+
+int rq_state_words() { return kRqStateWords; }
+int rq_word_rho() { return kRho; }
+int rq_word_gmg() { return kGMG; }
+
+// partials: at least 8 * 4096 doubles
+void launch_rq_pass1(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const double* x, const double* gv, const double* pold, double* pnew,
+                     double* state, int init, int robust, double* partials) {
+  int nblocks;
+  if (march_ok(g, A, Mo, m_identity, x, gv, pold, pnew, x)) {
+    const dim3 b(g.nc >= 512 ? kRqThreads : 64, 1, 1);
+    const unsigned gx = (unsigned)((g.nc / 2 + b.x - 1) / b.x);
+    long rows = 32;
+    while ((long)gx * ((g.nr + rows - 1) / rows) > 4096) rows *= 2;
+    const dim3 grid(gx, (unsigned)((g.nr + rows - 1) / rows), 1);
+    nblocks = (int)(grid.x * grid.y);
+    const int mm = m_identity ? 0 : 1;
+    switch (A.nterms) {
+      case 1: launch_pass1_ma<1>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      case 2: launch_pass1_ma<2>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      case 3: launch_pass1_ma<3>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      default: launch_pass1_ma<4>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+    }
+  } else {
+    const long n = g.nr * g.nc;
+    long blocks = (n + kRqThreads - 1) / kRqThreads;
+    if (blocks > 1024) blocks = 1024;
+    nblocks = (int)blocks;
+    hipLaunchKernelGGL(k_rq_pass1_point, dim3((unsigned)blocks), dim3(kRqThreads), 0, s, g, A, Mo, m_identity, x, gv, pold, pnew, state, init, partials, nblocks);
+  }
+  hipLaunchKernelGGL(k_rq_scalars1, dim3(1), dim3(kRqThreads), 0, s, partials, nblocks, state, init, robust);
+}
+
+// pass 2 without its scalars (the caller may have to put <g, M g> into the state first)
+int launch_rq_pass2(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const double* x, const double* p, double* xnew, double* gout, double* state,
+                    int init, double* partials) {
+  int nblocks;
+  if (march_ok(g, A, Mo, m_identity, x, p, xnew, gout, x)) {
+    const dim3 b(g.nc >= 512 ? kRqThreads : 64, 1, 1);
+    const unsigned gx = (unsigned)((g.nc / 2 + b.x - 1) / b.x);
+    long rows = 32;
+    while ((long)gx * ((g.nr + rows - 1) / rows) > 4096) rows *= 2;
+    const dim3 grid(gx, (unsigned)((g.nr + rows - 1) / rows), 1);
+    nblocks = (int)(grid.x * grid.y);
+    const int mm = m_identity ? 0 : 1;
+    switch (A.nterms) {
+      case 1: launch_pass2_ma<1>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      case 2: launch_pass2_ma<2>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      case 3: launch_pass2_ma<3>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      default: launch_pass2_ma<4>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+    }
+  } else {
+    const long n = g.nr * g.nc;
+    long blocks = (n + kRqThreads - 1) / kRqThreads;
+    if (blocks > 1024) blocks = 1024;
+    nblocks = (int)blocks;
+    hipLaunchKernelGGL(k_rq_pass2_point, dim3((unsigned)blocks), dim3(kRqThreads), 0, s, g, A, Mo, m_identity, x, p, xnew, gout, state, init, partials, nblocks);
+  }
+  return nblocks;
+}
+
+void launch_rq_scalars2(hipStream_t s, const double* partials, int nblocks, double* state, int m_identity, int init) {
+  hipLaunchKernelGGL(k_rq_scalars2, dim3(1), dim3(kRqThreads), 0, s, partials, nblocks, state, m_identity, init);
+}
+
+void launch_rq_store(hipStream_t s, double* state, int word, const double* value) { hipLaunchKernelGGL(k_rq_store, dim3(1), dim3(1), 0, s, state, word, value); }
+
+}  // namespace mgcmt

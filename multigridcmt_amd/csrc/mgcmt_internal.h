@@ -140,6 +140,20 @@ void launch_gram(hipStream_t s, long n, const double* const* v, int nv, double* 
 void launch_lincomb(hipStream_t s, long n, const double* const* v, const double* c, int nt, double* dst);
 bool mgs_small_fits(long n);
 
+// Rayleigh-quotient minimisation as two passes per step (kernels_rq.hip); state: rq_state_words() doubles on the device,
+// partials: at least 8 * 4096 doubles.  init: 1 = the initial pair (p = 0: rho and g of the start vector), 2 = the first
+// step (p = -g, p_old not read), 0 = a step.  launch_rq_pass1 ends with the step's scalars (delta, rho of x + delta p);
+// launch_rq_pass2 returns the number of partial sums per result for launch_rq_scalars2 (rho, beta), which the caller
+// runs after <g, M g> is in state[rq_word_gmg()] when M is not the identity.
+int rq_state_words();
+int rq_word_rho();
+int rq_word_gmg();
+void launch_rq_pass1(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const double* x, const double* gv, const double* pold, double* pnew,
+                     double* state, int init, int robust, double* partials);
+int launch_rq_pass2(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const double* x, const double* p, double* xnew, double* gout, double* state,
+                    int init, double* partials);
+void launch_rq_scalars2(hipStream_t s, const double* partials, int nblocks, double* state, int m_identity, int init);
+
 // the levels of at most 32 x 32 points of a V-cycle in one launch (kernels_tail.hip)
 constexpr int kTailMaxLevels = 6;
 struct TailArgs {

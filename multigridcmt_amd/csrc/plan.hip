@@ -856,6 +856,7 @@ int mgcmt_plan_destroy(mgcmt_plan* p) {
     if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
   if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
   if (p->d_rq) (void)hipFree(p->d_rq);
+  if (p->d_rqstate) (void)hipFree(p->d_rqstate);
   if (p->lex_carry) (void)hipFree(p->lex_carry);
   if (p->lex_sync) (void)hipFree(p->lex_sync);
   if (p->d_shifts) (void)hipFree(p->d_shifts);
@@ -1203,6 +1204,69 @@ int mgcmt_rayleigh_residual(mgcmt_plan* p, int l, int slot, int k, double* rq_ou
     const double vv = packed[(size_t)q * kPairs + 0], vr = packed[(size_t)q * kPairs + 1], rr = packed[(size_t)q * kPairs + kGramMaxVectors];
     if (rq_out) rq_out[q] = p->h_shifts[q] + vr / vv;
     if (res_out) res_out[q] = std::sqrt(rr);
+  }
+  return MGCMT_OK;
+}
+
+// rqmin (MGCMTSolver.py:17-57) on `level`, entirely on the device: two passes over the data per step (kernels_rq.hip), the
+// 2 x 2 pencil solved by one workgroup, no host round trip; the start vector is vecs[0] of `slot`, which also receives
+// the result; vecs[1..5]: five more vectors of the slot as work space (x and p are ping-ponged; g; one for M g).
+int mgcmt_rqmin(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, int robust, double* rho_out, void* stream) {
+  MG_TRY(check_level(p, l));
+  if (!vecs || nu < 0) return fail(MGCMT_ERR_INVALID, "rqmin: null vector list or negative step count");
+  for (int a = 0; a < 6; ++a) {
+    MG_TRY(check_vec(p, l, slot, vecs[a]));
+    for (int b = 0; b < a; ++b)
+      if (vecs[a] == vecs[b]) return fail(MGCMT_ERR_INVALID, "rqmin: the six vectors must be distinct");
+  }
+  MG_TRY(ensure_slot(p, l, slot));
+  hipStream_t s = S(stream);
+  if (!p->d_rqstate) {
+    MG_HIP(hipMalloc((void**)&p->d_rqstate, sizeof(double) * rq_state_words()));
+    MG_HIP(hipMemset(p->d_rqstate, 0, sizeof(double) * rq_state_words()));
+  }
+  const Level& L = p->levels[l];
+  const KOp& A = L.dA.k;
+  // M: the plan's mass operator; none, or one whose factors are identities, is the identity (no application at all)
+  bool m_identity = !p->has_mass;
+  if (p->has_mass) {
+    auto is_identity = [](const Tri& t) {
+      for (int64_t i = 0; i < t.n; ++i)
+        if (t.di(i) != 1.0 || (i > 0 && t.lo(i) != 0.0) || (i + 1 < t.n && t.up(i) != 0.0)) return false;
+      return true;
+    };
+    m_identity = L.hM.nterms == 1 && is_identity(L.hM.X[0]) && is_identity(L.hM.Y[0]);
+  }
+  const KOp& Mo = p->has_mass ? L.dM.k : A;  // (not read when M is the identity)
+  const KGrid g = p->kgrid(l);
+  double* x = p->kvec(l, slot, vecs[0]).p;
+  double* xalt = p->kvec(l, slot, vecs[1]).p;
+  double* pv = p->kvec(l, slot, vecs[2]).p;
+  double* palt = p->kvec(l, slot, vecs[3]).p;
+  double* gv = p->kvec(l, slot, vecs[4]).p;
+  double* tmp = p->kvec(l, slot, vecs[5]).p;
+  double* st = p->d_rqstate;
+  double* part = p->d_partials;
+  double* part_dot = p->d_partials + 40000;  // (d_partials holds 67584 doubles: 8 x 4096 for the passes, 1024 for the dot)
+  const long n = p->interior(l);
+  double* x0 = x;
+  for (int it = -1; it < nu; ++it) {
+    const int init = it < 0 ? 1 : (it == 0 ? 2 : 0);
+    launch_rq_pass1(s, g, A, Mo, m_identity ? 1 : 0, x, gv, pv, palt, st, init, robust, part);
+    if (init != 1) std::swap(pv, palt);
+    const int nb = launch_rq_pass2(s, g, A, Mo, m_identity ? 1 : 0, x, pv, xalt, gv, st, init, part);
+    std::swap(x, xalt);
+    if (!m_identity) {
+      launch_apply(s, g, Mo, KVec{gv, 0}, KVec{tmp, 0}, p->d_zero, 1);
+      launch_dots(s, n, gv, tmp, 0, 1, part_dot, st + rq_word_gmg());
+    }
+    launch_rq_scalars2(s, part, nb, st, m_identity ? 1 : 0, init);
+  }
+  MG_TRY(post_launch());
+  if (x != x0) MG_HIP(hipMemcpyAsync(x0, x, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+  if (rho_out) {
+    MG_HIP(hipMemcpyAsync(rho_out, st + rq_word_rho(), sizeof(double), hipMemcpyDeviceToHost, s));
+    MG_HIP(hipStreamSynchronize(s));
   }
   return MGCMT_OK;
 }

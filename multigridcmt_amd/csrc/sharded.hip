@@ -400,7 +400,7 @@ static int comm_common(mgcmt_plan* p, int rank, int nranks, ShardComm** out) {
   // oversubscribed and time-sliced (rocprofv3 trace: profiles/r03_rank_share_priority_stream_oversubscribed.txt).
   // MGCMT_COMM_PRIORITY=1 selects the priority stream (A/B measurements).
   const char* pe = getenv("MGCMT_COMM_PRIORITY");
-  hipError_t e = hipErrorUnknown;
+  hipError_t e = hipErrorInvalidValue;  // (anything but success: no priority stream asked for)
   if (pe && pe[0] == '1') {
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);

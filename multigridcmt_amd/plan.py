@@ -185,6 +185,14 @@ class Plan:
         check(_lib.lib().mgcmt_rayleigh_residual(self._h, level, slot, k, as_dp(rq), as_dp(res), stream))
         return rq, res
 
+    def rqmin(self, level, slot, vecs, nu, robust=False, want_rho=True, stream=None):
+        """nu steps of the reference's rqmin (MGCMTSolver.py:17-57) on `level`, resident on the device (mgcmt_rqmin): vecs[0]
+        of `slot` is the iterate, vecs[1..5] work space.  Returns rho (one synchronisation) or None (want_rho=False: none)."""
+        v = (ctypes.c_int * 6)(*[int(i) for i in vecs])
+        rho = c_double(0.0)
+        check(_lib.lib().mgcmt_rqmin(self._h, level, slot, v, int(nu), 1 if robust else 0, ctypes.byref(rho) if want_rho else None, stream))
+        return rho.value if want_rho else None
+
     def lincomb(self, level, terms, dst, stream=None):
         """dst <- sum of coeff * (slot, vec) over `terms` = [(coeff, (slot, vec)), ...] (at most four)."""
         nt = len(terms)

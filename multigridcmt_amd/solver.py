@@ -440,64 +440,18 @@ class MGCMTSolver:
     _X, _P, _G, _GOLD, _AX, _AP, _MX, _MP, _TMP, _TMP2 = range(10)
     _RQ_REGS = 10
 
-    def _rqmin_device(self, plan, level, nu, robust=False):
-        """rqmin (MGCMTSolver.py:17-57) on the registers of `level`; x is register _X.  The vector work (6 operator
-        applications and a handful of fused passes per step) runs on the GPU: every group of inner products the
-        reference takes one by one (:19-21, :34-35, :44-47) is ONE Gram-matrix pass with one host round trip
-        (mgcmt_gram), every update one fused linear combination; the 2x2 generalised eigenproblem on span{x, p}
-        (:48-50) is solved on the host."""
-        V = SLOT_V
-        X, P, G, GOLD, AX, AP, MX, MP, TMP, TMP2 = [(V, r) for r in range(10)]
-
-        def rayleigh():                          # A x, M x and rho = <x,Ax>/<x,Mx>
-            plan.apply(level, X, AX, op=OP_A)
-            plan.apply(level, X, MX, op=OP_M)
-            g = plan.gram(level, [X, AX, MX])
-            return g[0, 1] / g[0, 2]
-
-        def gradient(rho):                       # g = 2 (A x - rho M x)
-            plan.lincomb(level, [(2.0, AX), (-2.0 * rho, MX)], G)
-
-        rho = rayleigh()
-        plan.copy(level, X[0], X[1], GOLD[0], GOLD[1])
-        gradient(rho)
-        plan.copy(level, X[0], X[1], P[0], P[1])
-        for it in range(nu):
-            if it == 0:
-                plan.lincomb(level, [(-1.0, G)], P)
-            else:
-                plan.apply(level, G, TMP, op=OP_M)
-                plan.apply(level, GOLD, TMP2, op=OP_M)
-                gg = plan.gram(level, [G, TMP, GOLD, TMP2])
-                beta = gg[0, 1] / gg[2, 3]
-                plan.lincomb(level, [(beta, P), (-1.0, G)], P)
-            plan.apply(level, P, AP, op=OP_A)                  # (A x, M x are those of the last rayleigh())
-            plan.apply(level, P, MP, op=OP_M)
-            gm = plan.gram(level, [X, P, AX, AP, MX, MP])
-            R = np.array([[gm[0, 2], gm[0, 3]], [gm[1, 2], gm[1, 3]]])
-            RM = np.array([[gm[0, 4], gm[0, 5]], [gm[1, 4], gm[1, 5]]])
-            if robust:
-                # repaired variant ((f)4): a degenerate 2x2 pencil — the search direction vanished or is parallel to x, as
-                # happens with two orthogonal columns on a 2-point grid (the reference then dies inside eig with
-                # "array must not contain infs or NaNs", SURVEY §8c) — ends the minimisation on this level instead
-                RM_s = 0.5 * (RM + RM.T)
-                scale = max(abs(RM_s[0, 0]), 1e-300)
-                if not np.all(np.isfinite(R)) or not np.all(np.isfinite(RM_s)) or RM_s[1, 1] <= 1e-28 * scale or \
-                        np.linalg.det(RM_s) <= 1e-14 * RM_s[0, 0] * RM_s[1, 1]:
-                    break
-                w, vecs = scipy.linalg.eigh(0.5 * (R + R.T), b=RM_s)
-                y = vecs[:, 0]
-                if abs(y[0]) <= 1e-14 * abs(y[1]):
-                    break
-            else:
-                w, vecs = scipy.linalg.eig(R, b=RM)
-                y = vecs[:, np.argmin(w)]
-            delta = float(np.real(y[1] / y[0]))
-            plan.axpy(level, delta, P, X)
-            rho = rayleigh()
-            plan.copy(level, G[0], G[1], GOLD[0], GOLD[1])
-            gradient(rho)
-        return rho
+    def _rqmin_device(self, plan, level, nu, robust=False, want_rho=True):
+        """rqmin (MGCMTSolver.py:17-57) on the registers of `level`; x is register _X.  Resident on the device
+        (mgcmt_rqmin, csrc/kernels_rq.hip): per step two passes over the data — p = -g + beta p_old formed on the fly, A and M
+        applied to x and p in registers with the eight inner products of :33-46; then x + delta p with its gradient and the
+        next step's inner products — the 2 x 2 generalised eigenproblem of :48-50 solved in closed form by one workgroup,
+        and no host round trip (the round-2 form took six operator applications, three Gram passes, four vector updates
+        and three round trips per step: ~300 B per point against 64).  ``robust`` (the repaired variants, (f)4): a
+        degenerate pencil — the search direction vanished or is parallel to x, as happens with two orthogonal columns on a
+        2-point grid, where the reference dies inside eig with "array must not contain infs or NaNs"  — ends
+        the minimisation on this level.  want_rho=False: nothing synchronises."""
+        return plan.rqmin(level, SLOT_V, [self._X, self._TMP, self._P, self._TMP2, self._G, self._GOLD], int(nu), robust=robust,
+                          want_rho=want_rho)
 
     def _rq_plan(self, A, M, nmin, dimension=None):
         if M is None:
@@ -520,12 +474,14 @@ class MGCMTSolver:
         return plan.download(0, SLOT_V, self._X), rho
 
     def _rqmg_levels(self, plan, level, nu1, nu2, robust=False):
-        rho = self._rqmin_device(plan, level, nu1, robust)
-        if level + 1 < plan.num_levels:
+        """(the host sees one number per cycle: the Rayleigh quotient of the finest level's last minimisation)"""
+        last = level + 1 >= plan.num_levels
+        rho = self._rqmin_device(plan, level, nu1, robust, want_rho=last and level == 0)
+        if not last:
             plan.restrict(level, (SLOT_V, self._X), (SLOT_V, self._X))             # k_coarse = R k   (:113)
-            _, rho = self._rqmg_levels(plan, level + 1, nu1, nu2, robust)
+            self._rqmg_levels(plan, level + 1, nu1, nu2, robust)
             plan.prolong(level, (SLOT_V, self._X), (SLOT_V, self._X), accumulate=True)  # k += P c   (:116-118)
-            rho = self._rqmin_device(plan, level, nu2, robust)
+            rho = self._rqmin_device(plan, level, nu2, robust, want_rho=level == 0)
         return None, rho
 
     def vcycle_rqmg(self, x, A, M, nu1=4, nu2=4, nmin=2):
@@ -565,7 +521,7 @@ class MGCMTSolver:
     def _rqmg2_levels(self, plan, level, nv, nu1, nu2, robust=False):
         for i in range(nv):
             plan.copy(level, SLOT_W, i, SLOT_V, self._X)
-            self._rqmin_device(plan, level, nu1, robust)
+            self._rqmin_device(plan, level, nu1, robust, want_rho=False)
             plan.copy(level, SLOT_V, self._X, SLOT_W, i)
         if level == 0:
             for _ in range(4):
@@ -577,7 +533,7 @@ class MGCMTSolver:
             for i in range(nv):
                 plan.prolong(level, (SLOT_W, i), (SLOT_W, i), accumulate=True)
                 plan.copy(level, SLOT_W, i, SLOT_V, self._X)
-                self._rqmin_device(plan, level, nu2, robust)
+                self._rqmin_device(plan, level, nu2, robust, want_rho=False)
                 plan.copy(level, SLOT_V, self._X, SLOT_W, i)
 
     def twogridrqmin(self, A, v0, M, nu1=4, nu2=4, *, repaired=False):
