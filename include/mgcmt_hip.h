@@ -180,6 +180,11 @@ int mgcmt_ritz_pair(mgcmt_plan* plan, int level, int x_slot, int x_vec, int w_sl
  * infinities (the repaired variants).  rho_out (may be NULL: nothing synchronises then): the Rayleigh quotient of the
  * result (:53). */
 int mgcmt_rqmin(mgcmt_plan* plan, int level, int slot, const int* vecs, int nu, int robust, double* rho_out, void* stream);
+/* vcycle_rqmg (MGCMTSolver.py:99-122) from the finest level: rqmin with nu1 steps, the iterate restricted (:113), the same on
+ * the Galerkin pair (R A P, R M P) of every coarser level of the plan (the coarsest one only minimises), the interpolated
+ * coarse iterates added on the way up (:116-118) and nu2 more steps per level; vectors as for mgcmt_rqmin, on every level.
+ * One launch sequence without a host round trip, replayed as a HIP graph from its second call. */
+int mgcmt_vcycle_rqmg(mgcmt_plan* plan, int slot, const int* vecs, int nu1, int nu2, int robust, double* rho_out, void* stream);
 /* dst = sum_t coeffs[t] * (slots[t], vecs[t]), 1 <= nterms <= 4; dst may be one of the inputs (the updates
  * x <- x + delta p, MGCMTSolver.py:52, and the residual A x - rho M x, :22-23, in one pass each) */
 int mgcmt_lincomb(mgcmt_plan* plan, int level, int nterms, const double* coeffs, const int* slots, const int* vecs, int dst_slot,

@@ -96,6 +96,7 @@ _SIGNATURES = {
     "mgcmt_rayleigh_residual": (c_int, [c_void_p, c_int, c_int, c_int, _dp, _dp, c_void_p]),
     "mgcmt_ritz_pair": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _dp, c_void_p]),
     "mgcmt_rqmin": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, _dp, c_void_p]),
+    "mgcmt_vcycle_rqmg": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _dp, c_void_p]),
     "mgcmt_lincomb": (c_int, [c_void_p, c_int, c_int, _dp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_void_p]),
     "mgcmt_scale": (c_int, [c_void_p, c_int, c_double, c_int, c_int, c_void_p]),
     "mgcmt_block_gram": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int), c_int, POINTER(c_int), POINTER(c_int),

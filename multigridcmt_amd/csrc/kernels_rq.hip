@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2(KGrid g, KOp A, KOp Mo,
       apply2<MA>(A, fa, i, xn, xc, xs, axa, axb);
       apply2<MM>(Mo, fm, i, xn, xc, xs, mxa, mxb);
       const double ga = 2.0 * (axa - rho * mxa), gb = 2.0 * (axb - rho * mxb);
-      *reinterpret_cast<double2*>(xnew + i * nc + j) = make_double2(xc.a, xc.b);
+      if (init != 1) *reinterpret_cast<double2*>(xnew + i * nc + j) = make_double2(xc.a, xc.b);  // (the initial pair: x' = x stays where it is)
       *reinterpret_cast<double2*>(gout + i * nc + j) = make_double2(ga, gb);
       acc[0] += xc.a * axa + xc.b * axb;
       acc[1] += xc.a * mxa + xc.b * mxb;
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2_point(KGrid g, KOp A, K
     const double xc = pp ? x[k] + delta * pp[k] : x[k];
     const double ax = apply_point(A, 0, x, pp, 1.0, delta, g.nc, i, j), mx = apply_point(Mo, m_identity, x, pp, 1.0, delta, g.nc, i, j);
     const double gg = 2.0 * (ax - rho * mx);
-    xnew[k] = xc;
+    if (init != 1) xnew[k] = xc;
     gout[k] = gg;
     acc[0] += xc * ax;
     acc[1] += xc * mx;
@@ -305,30 +305,29 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2_point(KGrid g, KOp A, K
 
 // ---- scalars --------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ double reduce_result(const double* __restrict__ partials, int nblocks, double* s_buf) {
-  // one result's per-block partial sums: thread-strided, then a fixed tree (256 threads)
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) acc += partials[i];
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+// results' per-block partial sums -> s_out[q]: one wave per result (lane-strided, then a fixed shuffle tree); the block
+// has at least nq waves
+__device__ __forceinline__ void reduce_results(const double* __restrict__ partials, int nblocks, int nq, double* s_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < nq) {
+    const double* src = partials + (long)wave * nblocks;
+    double acc = 0.0;
+    for (int i = lane; i < nblocks; i += 64) acc += src[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+    if (lane == 0) s_out[wave] = acc;
+  }
   __syncthreads();
-  if (lane == 0) s_buf[wave] = acc;
-  __syncthreads();
-  double t = 0.0;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_buf[w];
-  return t;  // on every thread
 }
 
 // after pass 1: the 2 x 2 pencil R y = lambda RM y (MGCMTSolver.py:33-49), delta = y1 / y0 of the smaller eigenvalue
 // (:49-50), and rho of x + delta p by bilinearity (what pass 2 needs before it has formed x').  init: delta = 0.
 // robust (the repaired variants, solver.py): a degenerate pencil ends the minimisation on this level (delta = 0 from
 // here on) instead of producing infinities.
-__global__ void __launch_bounds__(kRqThreads) k_rq_scalars1(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int init,
+__global__ void __launch_bounds__(64 * kRqSums) k_rq_scalars1(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int init,
                                                            int robust) {
-  __shared__ double s_buf[kRqThreads / 64];
-  double s[kRqSums];
-  for (int q = 0; q < kRqSums; ++q) s[q] = reduce_result(partials + (long)q * nblocks, nblocks, s_buf);
+  __shared__ double s[kRqSums];
+  reduce_results(partials, nblocks, kRqSums, s);
   if (threadIdx.x != 0) return;
   for (int q = 0; q < kRqSums; ++q) state[q] = s[q];
   const double r00 = s[kS_xAx], r01 = s[kS_xAp], r10 = s[kS_pAx], r11 = s[kS_pAp];
@@ -376,11 +375,10 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_scalars1(const double* __rest
 }
 
 // after pass 2 (and, with M != I, after <g, M g> has been put into state[kGMG] by a dot product): rho (:53), beta (:31)
-__global__ void __launch_bounds__(kRqThreads) k_rq_scalars2(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int m_identity,
+__global__ void __launch_bounds__(256) k_rq_scalars2(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int m_identity,
                                                            int init) {
-  __shared__ double s_buf[kRqThreads / 64];
-  double s[3];
-  for (int q = 0; q < 3; ++q) s[q] = reduce_result(partials + (long)q * nblocks, nblocks, s_buf);
+  __shared__ double s[4];
+  reduce_results(partials, nblocks, 3, s);
   if (threadIdx.x != 0) return;
   state[kXAXn] = s[0];
   state[kXMXn] = s[1];
@@ -449,7 +447,7 @@ void launch_rq_pass1(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, cons
     nblocks = (int)blocks;
     hipLaunchKernelGGL(k_rq_pass1_point, dim3((unsigned)blocks), dim3(kRqThreads), 0, s, g, A, Mo, m_identity, x, gv, pold, pnew, state, init, partials, nblocks);
   }
-  hipLaunchKernelGGL(k_rq_scalars1, dim3(1), dim3(kRqThreads), 0, s, partials, nblocks, state, init, robust);
+  hipLaunchKernelGGL(k_rq_scalars1, dim3(1), dim3(64 * kRqSums), 0, s, partials, nblocks, state, init, robust);
 }
 
 // pass 2 without its scalars (the caller may have to put <g, M g> into the state first)
@@ -481,7 +479,7 @@ int launch_rq_pass2(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const
 }
 
 void launch_rq_scalars2(hipStream_t s, const double* partials, int nblocks, double* state, int m_identity, int init) {
-  hipLaunchKernelGGL(k_rq_scalars2, dim3(1), dim3(kRqThreads), 0, s, partials, nblocks, state, m_identity, init);
+  hipLaunchKernelGGL(k_rq_scalars2, dim3(1), dim3(256), 0, s, partials, nblocks, state, m_identity, init);
 }
 
 void launch_rq_store(hipStream_t s, double* state, int word, const double* value) { hipLaunchKernelGGL(k_rq_store, dim3(1), dim3(1), 0, s, state, word, value); }

@@ -1211,7 +1211,7 @@ int mgcmt_rayleigh_residual(mgcmt_plan* p, int l, int slot, int k, double* rq_ou
 // rqmin (MGCMTSolver.py:17-57) on `level`, entirely on the device: two passes over the data per step (kernels_rq.hip), the
 // 2 x 2 pencil solved by one workgroup, no host round trip; the start vector is vecs[0] of `slot`, which also receives
 // the result; vecs[1..5]: five more vectors of the slot as work space (x and p are ping-ponged; g; one for M g).
-int mgcmt_rqmin(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, int robust, double* rho_out, void* stream) {
+static int rqmin_check(mgcmt_plan* p, int l, int slot, const int* vecs, int nu) {
   MG_TRY(check_level(p, l));
   if (!vecs || nu < 0) return fail(MGCMT_ERR_INVALID, "rqmin: null vector list or negative step count");
   for (int a = 0; a < 6; ++a) {
@@ -1220,11 +1220,14 @@ int mgcmt_rqmin(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, int rob
       if (vecs[a] == vecs[b]) return fail(MGCMT_ERR_INVALID, "rqmin: the six vectors must be distinct");
   }
   MG_TRY(ensure_slot(p, l, slot));
-  hipStream_t s = S(stream);
   if (!p->d_rqstate) {
     MG_HIP(hipMalloc((void**)&p->d_rqstate, sizeof(double) * rq_state_words()));
     MG_HIP(hipMemset(p->d_rqstate, 0, sizeof(double) * rq_state_words()));
   }
+  return MGCMT_OK;
+}
+
+static int rqmin_impl(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, int robust, hipStream_t s) {
   const Level& L = p->levels[l];
   const KOp& A = L.dA.k;
   // M: the plan's mass operator; none, or one whose factors are identities, is the identity (no application at all)
@@ -1255,7 +1258,7 @@ int mgcmt_rqmin(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, int rob
     launch_rq_pass1(s, g, A, Mo, m_identity ? 1 : 0, x, gv, pv, palt, st, init, robust, part);
     if (init != 1) std::swap(pv, palt);
     const int nb = launch_rq_pass2(s, g, A, Mo, m_identity ? 1 : 0, x, pv, xalt, gv, st, init, part);
-    std::swap(x, xalt);
+    if (init != 1) std::swap(x, xalt);  // (the initial pair leaves x where it is)
     if (!m_identity) {
       launch_apply(s, g, Mo, KVec{gv, 0}, KVec{tmp, 0}, p->d_zero, 1);
       launch_dots(s, n, gv, tmp, 0, 1, part_dot, st + rq_word_gmg());
@@ -1264,11 +1267,88 @@ int mgcmt_rqmin(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, int rob
   }
   MG_TRY(post_launch());
   if (x != x0) MG_HIP(hipMemcpyAsync(x0, x, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-  if (rho_out) {
-    MG_HIP(hipMemcpyAsync(rho_out, st + rq_word_rho(), sizeof(double), hipMemcpyDeviceToHost, s));
-    MG_HIP(hipStreamSynchronize(s));
-  }
   return MGCMT_OK;
+}
+
+static int rq_result(mgcmt_plan* p, double* rho_out, hipStream_t s) {
+  if (!rho_out) return MGCMT_OK;
+  MG_HIP(hipMemcpyAsync(rho_out, p->d_rqstate + rq_word_rho(), sizeof(double), hipMemcpyDeviceToHost, s));
+  MG_HIP(hipStreamSynchronize(s));
+  return MGCMT_OK;
+}
+
+int mgcmt_rqmin(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, int robust, double* rho_out, void* stream) {
+  MG_TRY(rqmin_check(p, l, slot, vecs, nu));
+  MG_TRY(rqmin_impl(p, l, slot, vecs, nu, robust, S(stream)));
+  return rq_result(p, rho_out, S(stream));
+}
+
+// vcycle_rqmg (MGCMTSolver.py:99-122): rqmin, the ITERATE restricted (:113), the recursion on the Galerkin pair (R A P,
+// R M P) of the next level, the interpolated coarse iterate added (:116-118), rqmin again — down to the plan's coarsest
+// level, which only minimises.  One stream-ordered launch sequence without a host round trip, replayed as a HIP graph
+// from its second call (the levels below 512^2 are pure launch latency: seven launches per step).
+static int rqmg_body(mgcmt_plan* p, int l, int slot, const int* vecs, int nu1, int nu2, int robust, hipStream_t s) {
+  const int last = (int)p->levels.size() - 1;
+  MG_TRY(rqmin_impl(p, l, slot, vecs, nu1, robust, s));
+  if (l == last) return MGCMT_OK;
+  launch_restrict(s, p->kgrid(l), p->kgrid(l + 1), p->kvec(l, slot, vecs[0]), p->kvec(l + 1, slot, vecs[0]), 1);
+  MG_TRY(rqmg_body(p, l + 1, slot, vecs, nu1, nu2, robust, s));
+  launch_prolong(s, p->kgrid(l), p->kgrid(l + 1), p->kvec(l + 1, slot, vecs[0]), p->kvec(l, slot, vecs[0]), 1, 1);
+  MG_TRY(post_launch());
+  return rqmin_impl(p, l, slot, vecs, nu2, robust, s);
+}
+
+int mgcmt_vcycle_rqmg(mgcmt_plan* p, int slot, const int* vecs, int nu1, int nu2, int robust, double* rho_out, void* stream) {
+  if (!p) return fail(MGCMT_ERR_INVALID, "null plan");
+  if (nu1 < 0 || nu2 < 0) return fail(MGCMT_ERR_INVALID, "step counts must be >= 0");
+  for (int l = 0; l < (int)p->levels.size(); ++l) MG_TRY(rqmin_check(p, l, slot, vecs, nu1));
+  hipStream_t s = S(stream);
+  char buf[200];
+  snprintf(buf, sizeof(buf), "rqmg/%d/%d/%d/%d/%d,%d,%d,%d,%d,%d", nu1, nu2, robust, slot, vecs[0], vecs[1], vecs[2], vecs[3], vecs[4], vecs[5]);
+  const std::string params(buf);
+  std::string key = params;
+  for (const Level& L : p->levels) {
+    snprintf(buf, sizeof(buf), "|%p", (void*)L.base[slot]);
+    key += buf;
+  }
+  auto eager = [&]() {
+    MG_TRY(rqmg_body(p, 0, slot, vecs, nu1, nu2, robust, s));
+    return rq_result(p, rho_out, s);
+  };
+  if (!p->use_graph) return eager();
+  auto hit = p->graphs.find(key);
+  if (hit != p->graphs.end()) {
+    MG_HIP(hipGraphLaunch(hit->second.exec, s));
+    return rq_result(p, rho_out, s);
+  }
+  if (p->cycle_seen[params]++ == 0) return eager();  // the first call allocates and queries occupancies
+  if (!p->capture_stream && hipStreamCreate(&p->capture_stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return eager();
+  }
+  if (hipStreamBeginCapture(p->capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return eager();
+  }
+  const int rc = rqmg_body(p, 0, slot, vecs, nu1, nu2, robust, p->capture_stream);
+  hipGraph_t graph = nullptr;
+  const hipError_t end = hipStreamEndCapture(p->capture_stream, &graph);
+  if (rc != MGCMT_OK || end != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    if (rc != MGCMT_OK) return rc;
+    return eager();  // (nothing ran during the capture and the body keeps no host-side state: run it for real)
+  }
+  mgcmt_plan::CycleGraph cg;
+  const hipError_t inst = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (inst != hipSuccess) {
+    (void)hipGetLastError();
+    return eager();
+  }
+  MG_HIP(hipGraphLaunch(cg.exec, s));
+  p->graphs[key] = cg;
+  return rq_result(p, rho_out, s);
 }
 
 int mgcmt_lincomb(mgcmt_plan* p, int l, int nterms, const double* coeffs, const int* slots, const int* vecs, int dst_slot, int dst_vec,

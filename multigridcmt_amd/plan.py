@@ -193,6 +193,14 @@ class Plan:
         check(_lib.lib().mgcmt_rqmin(self._h, level, slot, v, int(nu), 1 if robust else 0, ctypes.byref(rho) if want_rho else None, stream))
         return rho.value if want_rho else None
 
+    def vcycle_rqmg(self, slot, vecs, nu1, nu2, robust=False, want_rho=True, stream=None):
+        """One cycle of the reference's Rayleigh-quotient multigrid (MGCMTSolver.py:99-122) over all levels of the plan,
+        resident on the device (mgcmt_vcycle_rqmg); vecs as for rqmin, on every level."""
+        v = (ctypes.c_int * 6)(*[int(i) for i in vecs])
+        rho = c_double(0.0)
+        check(_lib.lib().mgcmt_vcycle_rqmg(self._h, slot, v, int(nu1), int(nu2), 1 if robust else 0, ctypes.byref(rho) if want_rho else None, stream))
+        return rho.value if want_rho else None
+
     def lincomb(self, level, terms, dst, stream=None):
         """dst <- sum of coeff * (slot, vec) over `terms` = [(coeff, (slot, vec)), ...] (at most four)."""
         nt = len(terms)

@@ -450,8 +450,11 @@ class MGCMTSolver:
         degenerate pencil — the search direction vanished or is parallel to x, as happens with two orthogonal columns on a
         2-point grid, where the reference dies inside eig with "array must not contain infs or NaNs"  — ends
         the minimisation on this level.  want_rho=False: nothing synchronises."""
-        return plan.rqmin(level, SLOT_V, [self._X, self._TMP, self._P, self._TMP2, self._G, self._GOLD], int(nu), robust=robust,
-                          want_rho=want_rho)
+        return plan.rqmin(level, SLOT_V, self._rq_vecs(), int(nu), robust=robust, want_rho=want_rho)
+
+    def _rq_vecs(self):
+        """registers of mgcmt_rqmin: the iterate, its ping-pong partner, p and its partner, g, one for M g"""
+        return [self._X, self._TMP, self._P, self._TMP2, self._G, self._GOLD]
 
     def _rq_plan(self, A, M, nmin, dimension=None):
         if M is None:
@@ -474,14 +477,18 @@ class MGCMTSolver:
         return plan.download(0, SLOT_V, self._X), rho
 
     def _rqmg_levels(self, plan, level, nu1, nu2, robust=False):
-        """(the host sees one number per cycle: the Rayleigh quotient of the finest level's last minimisation)"""
+        """vcycle_rqmg's recursion (MGCMTSolver.py:99-122) from `level` down.  From the finest level the whole cycle is one
+        call into the library (mgcmt_vcycle_rqmg: no host round trip, replayed as a HIP graph); the host sees one number
+        per cycle, the Rayleigh quotient of the finest level's last minimisation."""
+        if level == 0:
+            return None, plan.vcycle_rqmg(SLOT_V, self._rq_vecs(), nu1, nu2, robust=robust)
         last = level + 1 >= plan.num_levels
-        rho = self._rqmin_device(plan, level, nu1, robust, want_rho=last and level == 0)
+        rho = self._rqmin_device(plan, level, nu1, robust, want_rho=False)
         if not last:
             plan.restrict(level, (SLOT_V, self._X), (SLOT_V, self._X))             # k_coarse = R k   (:113)
             self._rqmg_levels(plan, level + 1, nu1, nu2, robust)
             plan.prolong(level, (SLOT_V, self._X), (SLOT_V, self._X), accumulate=True)  # k += P c   (:116-118)
-            rho = self._rqmin_device(plan, level, nu2, robust, want_rho=level == 0)
+            rho = self._rqmin_device(plan, level, nu2, robust, want_rho=False)
         return None, rho
 
     def vcycle_rqmg(self, x, A, M, nu1=4, nu2=4, nmin=2):
