@@ -54,7 +54,7 @@ __device__ __forceinline__ void load_fac(const KOp& op, long j, Fac<M>& f) {
     }
 }
 
-// (Op v) at (i, j) and (i, j+1) from the rows above / at / below; M == 0: the identity.  eval_point's expressions.
+// (Op v) at (i, j) and (i, j+1) from the rows above / at / below; M == 0: the identity.  eval_point's terms.
 template <int M>
 __device__ __forceinline__ void apply2(const KOp& op, const Fac<M>& f, long i, const Row4& n, const Row4& c, const Row4& s, double& ra, double& rb) {
   if (M == 0) {
@@ -62,28 +62,30 @@ __device__ __forceinline__ void apply2(const KOp& op, const Fac<M>& f, long i, c
     rb = c.b;
     return;
   }
+  // (explicit multiply-adds: the library is built with -ffp-contract=off, and on the Galerkin levels — every term a full
+  // 9-point stencil, M too — these passes are bound by the vector ALUs, not by memory)
   double offa = 0.0, offb = 0.0, da = 0.0, db = 0.0;
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const double* X = op.X[m] + i;
     const double xl = X[0], xd = X[op.ldx], xu = X[2 * op.ldx];
     {
-      const double rn = f.yl[m][0] * n.w + f.yd[m][0] * n.a + f.yu[m][0] * n.b;
-      const double rc = f.yl[m][0] * c.w + f.yu[m][0] * c.b;
-      const double rs = f.yl[m][0] * s.w + f.yd[m][0] * s.a + f.yu[m][0] * s.b;
-      offa += xl * rn + xd * rc + xu * rs;
-      da += xd * f.yd[m][0];
+      const double rn = fma(f.yu[m][0], n.b, fma(f.yd[m][0], n.a, f.yl[m][0] * n.w));
+      const double rc = fma(f.yu[m][0], c.b, f.yl[m][0] * c.w);
+      const double rs = fma(f.yu[m][0], s.b, fma(f.yd[m][0], s.a, f.yl[m][0] * s.w));
+      offa = fma(xu, rs, fma(xd, rc, fma(xl, rn, offa)));
+      da = fma(xd, f.yd[m][0], da);
     }
     {
-      const double rn = f.yl[m][1] * n.a + f.yd[m][1] * n.b + f.yu[m][1] * n.e;
-      const double rc = f.yl[m][1] * c.a + f.yu[m][1] * c.e;
-      const double rs = f.yl[m][1] * s.a + f.yd[m][1] * s.b + f.yu[m][1] * s.e;
-      offb += xl * rn + xd * rc + xu * rs;
-      db += xd * f.yd[m][1];
+      const double rn = fma(f.yu[m][1], n.e, fma(f.yd[m][1], n.b, f.yl[m][1] * n.a));
+      const double rc = fma(f.yu[m][1], c.e, f.yl[m][1] * c.a);
+      const double rs = fma(f.yu[m][1], s.e, fma(f.yd[m][1], s.b, f.yl[m][1] * s.a));
+      offb = fma(xu, rs, fma(xd, rc, fma(xl, rn, offb)));
+      db = fma(xd, f.yd[m][1], db);
     }
   }
-  ra = offa + da * c.a;
-  rb = offb + db * c.b;
+  ra = fma(da, c.a, offa);
+  rb = fma(db, c.b, offb);
 }
 
 constexpr int kRqThreads = 256;
@@ -125,10 +127,10 @@ __device__ __forceinline__ Row4 load4(const double* __restrict__ u, const double
   if (w) {
     const double2 d = *reinterpret_cast<const double2*>(w + i * nc + j);
     const double dw = hw ? w[i * nc + jw] : 0.0, de = he ? w[i * nc + je] : 0.0;
-    r.w = cu * r.w + cw * dw;
-    r.a = cu * r.a + cw * d.x;
-    r.b = cu * r.b + cw * d.y;
-    r.e = cu * r.e + cw * de;
+    r.w = fma(cw, dw, cu * r.w);
+    r.a = fma(cw, d.x, cu * r.a);
+    r.b = fma(cw, d.y, cu * r.b);
+    r.e = fma(cw, de, cu * r.e);
   }
   return r;
 }
@@ -167,14 +169,14 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass1(KGrid g, KOp A, KOp Mo,
       apply2<MA>(A, fa, i, pn, pc, ps, apa, apb);
       apply2<MM>(Mo, fm, i, xn, xc, xs, mxa, mxb);
       apply2<MM>(Mo, fm, i, pn, pc, ps, mpa, mpb);
-      acc[kS_xAx] += xc.a * axa + xc.b * axb;
-      acc[kS_xAp] += xc.a * apa + xc.b * apb;
-      acc[kS_pAx] += pc.a * axa + pc.b * axb;
-      acc[kS_pAp] += pc.a * apa + pc.b * apb;
-      acc[kS_xMx] += xc.a * mxa + xc.b * mxb;
-      acc[kS_xMp] += xc.a * mpa + xc.b * mpb;
-      acc[kS_pMx] += pc.a * mxa + pc.b * mxb;
-      acc[kS_pMp] += pc.a * mpa + pc.b * mpb;
+      acc[kS_xAx] = fma(xc.b, axb, fma(xc.a, axa, acc[kS_xAx]));
+      acc[kS_xAp] = fma(xc.b, apb, fma(xc.a, apa, acc[kS_xAp]));
+      acc[kS_pAx] = fma(pc.b, axb, fma(pc.a, axa, acc[kS_pAx]));
+      acc[kS_pAp] = fma(pc.b, apb, fma(pc.a, apa, acc[kS_pAp]));
+      acc[kS_xMx] = fma(xc.b, mxb, fma(xc.a, mxa, acc[kS_xMx]));
+      acc[kS_xMp] = fma(xc.b, mpb, fma(xc.a, mpa, acc[kS_xMp]));
+      acc[kS_pMx] = fma(pc.b, mxb, fma(pc.a, mxa, acc[kS_pMx]));
+      acc[kS_pMp] = fma(pc.b, mpb, fma(pc.a, mpa, acc[kS_pMp]));
       if (init != 1) *reinterpret_cast<double2*>(pnew + i * nc + j) = make_double2(pc.a, pc.b);
       xn = xc;
       xc = xs;
@@ -214,9 +216,9 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2(KGrid g, KOp A, KOp Mo,
       const double ga = 2.0 * (axa - rho * mxa), gb = 2.0 * (axb - rho * mxb);
       if (init != 1) *reinterpret_cast<double2*>(xnew + i * nc + j) = make_double2(xc.a, xc.b);  // (the initial pair: x' = x stays where it is)
       *reinterpret_cast<double2*>(gout + i * nc + j) = make_double2(ga, gb);
-      acc[0] += xc.a * axa + xc.b * axb;
-      acc[1] += xc.a * mxa + xc.b * mxb;
-      acc[2] += ga * ga + gb * gb;
+      acc[0] = fma(xc.b, axb, fma(xc.a, axa, acc[0]));
+      acc[1] = fma(xc.b, mxb, fma(xc.a, mxa, acc[1]));
+      acc[2] = fma(gb, gb, fma(ga, ga, acc[2]));
       xn = xc;
       xc = xs;
     }
