@@ -366,6 +366,9 @@ __global__ void __launch_bounds__(64 * kRqSums) k_rq_scalars1(const double* __re
     const double n2 = r10 - lam * m10, d2 = r11 - lam * m11;
     delta = -n2 / d2;
     if (!(fabs(delta) <= 1.7e308)) delta = -(r00 - lam * m00) / (r01 - lam * m01);
+    // p = 0 (a gradient that came out as exact zeros: x is an eigenvector to the last bit, as on a 2-point level after one
+    // step): the minimiser over span{x} is x — where the reference's eig would return NaNs, nothing is updated
+    if (!(fabs(delta) <= 1.7e308)) delta = 0.0;
     if (robust && !(fabs(delta) < 1e300)) {  // y0 = 0: the minimiser is p itself — the reference's ratio is infinite
       stop = true;
       delta = 0.0;
@@ -373,7 +376,8 @@ __global__ void __launch_bounds__(64 * kRqSums) k_rq_scalars1(const double* __re
   }
   state[kStop] = stop ? 1.0 : 0.0;
   state[kDelta] = delta;
-  state[kRhoLin] = (r00 + delta * (r01 + r10) + delta * delta * r11) / (m00 + delta * (m01 + m10) + delta * delta * m11);
+  const double rl = (r00 + delta * (r01 + r10) + delta * delta * r11) / (m00 + delta * (m01 + m10) + delta * delta * m11);
+  state[kRhoLin] = fabs(rl) <= 1.7e308 ? rl : r00 / m00;
 }
 
 // after pass 2 (and, with M != I, after <g, M g> has been put into state[kGMG] by a dot product): rho (:53), beta (:31)
@@ -388,7 +392,8 @@ __global__ void __launch_bounds__(256) k_rq_scalars2(const double* __restrict__ 
   state[kRho] = s[0] / s[1];
   const double gmg = m_identity ? s[2] : state[kGMG];
   // the first step takes p = -g (:29-30): beta = 0; afterwards <g,Mg> / <g_old,Mg_old>
-  state[kBeta] = init == 1 ? 0.0 : gmg / state[kGMGprev];
+  const double prev = state[kGMGprev];
+  state[kBeta] = (init == 1 || !(prev != 0.0)) ? 0.0 : gmg / prev;  // (a previous gradient of exact zeros: restart from -g)
   state[kGMGprev] = gmg;
   state[kGMG] = gmg;
 }

@@ -282,29 +282,33 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
 
 
 def block_eigensolve(op, k=4, cycles=12, nu=2, lowest=8, smoother="rb", seed=0, guesses=None, history=None, residuals=None,
-                     use_p=True, stats=None):
-    """SURVEY par. 8(f)4: the k lowest eigenpairs of a structured 2-D operator by BLOCKED Rayleigh-Ritz with a V-cycle
-    preconditioner — the reference's Rayleigh-quotient routines (rqmin's 2 x 2 problem over span{x, p},
-    MGCMTSolver.py:44-50; the dead vcycle_rqmg2, :59-94) carried to a block of k vectors with LOBPCG-style updates.  Not in
-    the reference: parity unpinned; checked against exact eigenvalues.
+                     use_p=True, stats=None, mass=None):
+    """SURVEY par. 8(f)4: the k lowest eigenpairs of a structured 2-D operator — of the pencil (A, M) with ``mass`` — by
+    BLOCKED Rayleigh-Ritz with a V-cycle preconditioner: the reference's Rayleigh-quotient routines (rqmin's 2 x 2 problem
+    over span{x, p} with its generalised form R y = lambda RM y, MGCMTSolver.py:33-50; the dead vcycle_rqmg2, :59-94, which
+    carries M alongside A, :78-79) carried to a block of k vectors with LOBPCG-style updates.  Not in the reference: parity
+    unpinned; checked against exact eigenvalues and scipy's eigsh.
 
-    Per iteration, all vectors resident in HBM:  R = A X - X diag(rho);  W = one V(nu, nu) cycle per column of R from a
-    zero start (k columns batched);  A W;  Rayleigh-Ritz over S = [X, W, P] (P: the previous update directions;
-    use_p=False gives blocked preconditioned steepest descent): the 3k x 3k pencil (S^T A S, S^T S) from six one-pass block
-    Gram products, its k lowest pairs on the host, then X, P, A X, A P updated by four tall-skinny products.  The host sees
-    Gram matrices only.  k <= 4.
+    Per iteration, all vectors resident in HBM:  R = A X - M X diag(rho);  W = one V(nu, nu) cycle of A per column of R
+    from a zero start (k columns batched);  A W, M W;  Rayleigh-Ritz over S = [X, W, P] (P: the previous update directions;
+    use_p=False gives blocked preconditioned steepest descent): the 3k x 3k pencil (S^T A S, S^T M S) from one-pass block
+    Gram products, its k lowest pairs on the host, then X, P and their images under A and M updated by tall-skinny
+    products.  The host sees Gram matrices only.  k <= 4.  ``mass``: a StructuredOperator (None: the identity — nothing of
+    M is then stored or applied).
 
-    Returns (eigenvalues, eigenvectors[n, k]); ``history`` receives the Ritz values after every iteration, ``residuals``
-    the norms ||A x_j - rho_j x_j||."""
+    Returns (eigenvalues, eigenvectors[n, k]) with X^T M X = I; ``history`` receives the Ritz values after every iteration,
+    ``residuals`` the norms ||A x_j - rho_j M x_j||."""
     from . import _lib
+    from ._lib import OP_M
     from .plan import get_plan
     k = int(k)
     if not 1 <= k <= 4:
         raise ValueError("block_eigensolve handles 1..4 eigenpairs at a time")
     kind, omega = (_lib.GS_MC, 1.0) if smoother == "rb" else (_lib.WJACOBI, 2. / 3.)
     V, F, W = _lib.SLOT_V, _lib.SLOT_F, _lib.SLOT_W
-    plan = get_plan(op, int(lowest), nvec=3 * k)
-    plan.set_shifts(np.zeros(3 * k))
+    gen = mass is not None
+    plan = get_plan(op, int(lowest), nvec=(5 if gen else 3) * k, mass=mass)
+    plan.set_shifts(np.zeros(plan.nvec))
     n = plan.size(0)
     # what must survive a cycle lives in slot W and in the columns of slot F the cycle does not use (a cycle may exchange
     # the storage of slots V and T, and uses T as its scratch)
@@ -315,16 +319,20 @@ def block_eigensolve(op, k=4, cycles=12, nu=2, lowest=8, smoother="rb", seed=0, 
     AP = [(F, k + j) for j in range(k)]
     AW = [(F, 2 * k + j) for j in range(k)]
     Wd = [(V, j) for j in range(k)]          # the cycle's output
+    # images under M (M = I: the vectors themselves)
+    MX = [(W, 3 * k + j) for j in range(k)] if gen else X
+    MP = [(W, 4 * k + j) for j in range(k)] if gen else P
+    MW = [(F, 3 * k + j) for j in range(k)] if gen else Wd
     rng = np.random.RandomState(seed)
     for j in range(k):
         plan.upload(0, W, j, rng.random_sample(n) if guesses is None else np.asarray(guesses)[:, j])
 
-    def ritz(S, AS, take):
-        """k lowest Ritz pairs of the pencil (S^T A S, S^T S); blocks of at most four columns per Gram product"""
+    def ritz(S, AS, MS, take):
+        """k lowest Ritz pairs of the pencil (S^T A S, S^T M S); blocks of at most four columns per Gram product"""
         m = len(S)
         G, H = np.zeros((m, m)), np.zeros((m, m))
         for c in range(0, m, 4):
-            G[:, c:c + 4] = plan.block_gram(0, S, S[c:c + 4])
+            G[:, c:c + 4] = plan.block_gram(0, S, MS[c:c + 4])
             H[:, c:c + 4] = plan.block_gram(0, S, AS[c:c + 4])
         G, H = 0.5 * (G + G.T), 0.5 * (H + H.T)
         d = 1.0 / np.sqrt(np.diag(G))                   # (scaling only: the pencil's eigenvectors are rescaled back)
@@ -334,30 +342,42 @@ def block_eigensolve(op, k=4, cycles=12, nu=2, lowest=8, smoother="rb", seed=0, 
     import time
     for j in range(k):
         plan.apply(0, X[j], AX[j])
-    rho, C = ritz(X, AX, k)
+        if gen:
+            plan.apply(0, X[j], MX[j], op=OP_M)
+    rho, C = ritz(X, AX, MX, k)
     plan.block_combine(0, X, X, C)
     plan.block_combine(0, AX, AX, C)
+    if gen:
+        plan.block_combine(0, MX, MX, C)
     have_p = False
     loop_start = time.perf_counter()
     for _ in range(int(cycles)):
         for j in range(k):
-            plan.lincomb(0, [(1.0, AX[j]), (-float(rho[j]), X[j])], R[j])
+            plan.lincomb(0, [(1.0, AX[j]), (-float(rho[j]), MX[j])], R[j])
         if residuals is not None:
             residuals.append(np.sqrt(np.diag(plan.block_gram(0, R, R))))
         plan.vcycle(nu, nu, kind, omega=omega, k=k, nu_coarse=nu, zero_start=True)
         for j in range(k):
             plan.apply(0, Wd[j], AW[j])
-        S, AS = (X + Wd + P, AX + AW + AP) if have_p else (X + Wd, AX + AW)
+            if gen:
+                plan.apply(0, Wd[j], MW[j], op=OP_M)
+        if have_p:
+            S, AS, MS = X + Wd + P, AX + AW + AP, MX + MW + MP
+        else:
+            S, AS, MS = X + Wd, AX + AW, MX + MW
         try:
-            rho, C = ritz(S, AS, k)
+            rho, C = ritz(S, AS, MS, k)
         except (scipy.linalg.LinAlgError, ValueError):   # the directions have become dependent: restart without P
-            S, AS = X + Wd, AX + AW
-            rho, C = ritz(S, AS, k)
-        # P' = [W, P] C_wp, X' = X C_x + P'  (and the same for their images under A): P is overwritten first, X uses the new P
+            S, AS, MS = X + Wd, AX + AW, MX + MW
+            rho, C = ritz(S, AS, MS, k)
+        # P' = [W, P] C_wp, X' = X C_x + P'  (and the same for their images under A and M): P is overwritten first, X uses the new P
         plan.block_combine(0, S[k:], P, C[k:])
         plan.block_combine(0, AS[k:], AP, C[k:])
         plan.block_combine(0, X + P, X, np.vstack([C[:k], np.eye(k)]))
         plan.block_combine(0, AX + AP, AX, np.vstack([C[:k], np.eye(k)]))
+        if gen:
+            plan.block_combine(0, MS[k:], MP, C[k:])
+            plan.block_combine(0, MX + MP, MX, np.vstack([C[:k], np.eye(k)]))
         have_p = bool(use_p)
         if history is not None:
             history.append(np.array(rho))

@@ -237,6 +237,30 @@ def main():
     rq["rqmg2_nmin4_rq_survey"] = np.array([0.963017800746613, 1.040538684849706])
     save("rqmin", **rq)
 
+    # ---- the same family with a NON-IDENTITY mass operator (the reference coarsens M alongside A: MGCMTSolver.py:78-79,
+    # 110-111): M = the linear finite-element mass matrix tridiag(1, 4, 1) / 6 ----
+    def fem_mass(n):
+        return sp.diags([np.full(n - 1, 1.0 / 6.0), np.full(n, 4.0 / 6.0), np.full(n - 1, 1.0 / 6.0)], [-1, 0, 1], format="csr")
+
+    rm = {"x0": x0, "X0": X0}
+    Mt64, Mt32 = fem_mass(64), fem_mass(32)
+    x, rho = solver.rqmin(A64, _c(x0), Mt64, nu=4)
+    rm["rqmin_x"], rm["rqmin_rho"] = np.real(x), np.real(rho)
+    x = _c(x0)
+    rhos = []
+    for _ in range(2):
+        x, rho = solver.vcycle_rqmg(x, A64, Mt64)
+        rhos.append(np.real(rho))
+    rm["rqmg_x"], rm["rqmg_rhos"] = np.real(x), np.array(rhos)
+    x, rho = solver.vcycle_rqmg(_c(x0), A64, Mt64, nu1=4, nu2=4, nmin=32)
+    rm["twogrid_x"], rm["twogrid_rho"] = np.real(x), np.real(rho)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X = solver.vcycle_rqmg2(X0.copy(), A32, Mt32, nmin=4)
+    rm["rqmg2_nmin4_X"] = X
+    rm["rqmg2_nmin4_rq"] = np.array([X[:, i] @ (A32 @ X[:, i]) / (X[:, i] @ (Mt32 @ X[:, i])) for i in range(2)])
+    save("rqmin_mass", **rm)
+
     # ---- driver re-enactments ----
     # 1DPotMatrixVcycle.py:14-80 at the script's own sizes (n = 128, guess 16, 10 pairs, 10 iterations)
     g, bad, k, iters = 128, 16, 10, 10

@@ -159,3 +159,27 @@ def test_block_eigensolve_square_well_against_eigsh(backend):
     vals, vecs = drivers.block_eigensolve(op, k=k, cycles=10, lowest=8)
     want = np.sort(sla.eigsh(op.tocsr(), k=k, which="SA")[0])
     assert np.allclose(vals, want, rtol=1e-9, atol=1e-9)
+
+
+def test_block_eigensolve_with_a_mass_operator(backend):
+    """SURVEY par. 8(f)4, generalised: the lowest pairs of A x = lambda M x with A the compact fourth-order (Mehrstellen)
+    9-point Laplacian and M its right-hand-side operator (operators.mehrstellen_mass) — the reference carries M through
+    its Rayleigh-quotient routines (MGCMTSolver.py:33-50,78-79) — against scipy's eigsh on the assembled pencil; the
+    eigenvalues are fourth-order accurate approximations of the continuum's (k^2 + l^2), which the 5-point operator with
+    M = I is not; vectors come back M-orthonormal.  Not in the reference: parity unpinned."""
+    import scipy.sparse.linalg as sla
+    from multigridcmt_amd.operators import laplacian_operator, mehrstellen_mass, mehrstellen_operator
+    g, k = 64, 3
+    A, M = mehrstellen_operator(g) * (-1 / np.pi ** 2), mehrstellen_mass(g)
+    hist, res = [], []
+    vals, vecs = drivers.block_eigensolve(A, k=k, cycles=12, lowest=8, mass=M, history=hist, residuals=res)
+    As, Ms = A.tocsr(), M.tocsr()
+    want = np.sort(sla.eigsh(As, k=k, M=Ms, sigma=0.0, which="LM")[0])
+    assert np.allclose(vals, want, rtol=1e-9, atol=1e-9), np.abs(vals - want)
+    assert np.abs(vecs.T @ (Ms @ vecs) - np.eye(k)).max() < 1e-9
+    assert np.abs(As @ vecs - (Ms @ vecs) * vals).max() < 1e-5 and res[-1].max() < res[0].max() * 1e-3
+    # the point of the generalised pencil: the lowest eigenvalue of the box (continuum: 2 in these units, Dirichlet ghosts
+    # at -1 and g: the box has g + 1 intervals of h = 1/g, so 2 g^2/(g+1)^2) is closer than the 5-point operator's
+    exact = 2.0 * g ** 2 / (g + 1.0) ** 2
+    five = drivers.exact_box_eigenvalues(g, "2d", 1)[0]
+    assert abs(vals[0] - exact) < 0.05 * abs(five - exact)

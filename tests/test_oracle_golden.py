@@ -195,6 +195,29 @@ def test_rqmin_family():
     assert np.allclose(rq, gold["rqmg2_nmin4_rq_survey"], rtol=0, atol=1e-9)
 
 
+def _fem_mass(n):
+    return sp.diags([np.full(n - 1, 1.0 / 6.0), np.full(n, 4.0 / 6.0), np.full(n - 1, 1.0 / 6.0)], [-1, 0, 1], format="csr")
+
+
+def test_rqmin_family_with_a_mass_operator():
+    """The same with M = the finite-element mass matrix tridiag(1, 4, 1) / 6: the reference coarsens M alongside A
+    (MGCMTSolver.py:78-79,110-111); fixture rqmin_mass.npz is the reference's own output."""
+    gold = load_golden("rqmin_mass")
+    A, M = H(64), _fem_mass(64)
+    x, rho = S.rqmin(A, gold["x0"], M, nu=4)
+    assert abs(np.real(rho) - float(gold["rqmin_rho"])) < 1e-10 and rel_err(np.real(x), gold["rqmin_x"]) < 1e-10
+    x = gold["x0"].copy()
+    for i in range(2):
+        x, rho = S.vcycle_rqmg(x, A, M)
+        assert abs(np.real(rho) - gold["rqmg_rhos"][i]) < 1e-10
+    assert rel_err(np.real(x), gold["rqmg_x"]) < 1e-9
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X = S.vcycle_rqmg2(gold["X0"], H(32), _fem_mass(32), nmin=4)
+    rq = [X[:, i] @ (H(32) @ X[:, i]) / (X[:, i] @ (_fem_mass(32) @ X[:, i])) for i in range(2)]
+    assert np.allclose(rq, gold["rqmg2_nmin4_rq"], rtol=0, atol=1e-9)
+
+
 def test_driver_reenactments():
     """Compute sections of 1DPotMatrixVcycle.py:42-80 and 2DPotMatrixVcycle.py:54-109 (reduced)."""
     for name, dim, g, low in (("driver_1dpot_matrix_vcycle", "1d", 128, 16), ("driver_2dpot_matrix_vcycle", "2d", 32, 4)):

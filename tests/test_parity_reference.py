@@ -242,6 +242,39 @@ def test_rqmin_family(trio):
         solver.twogridrqmin(A, gold["x0"], M)                          # dead code in the reference (:167)
 
 
+def test_rqmin_family_with_a_mass_operator(trio):
+    """rqmin / vcycle_rqmg / vcycle_rqmg2 with a NON-IDENTITY mass operator, M = the finite-element mass matrix
+    tridiag(1, 4, 1) / 6 (the reference coarsens M alongside A, MGCMTSolver.py:78-79,110-111) — reference outputs in
+    tests/golden/rqmin_mass.npz.  On the device every level applies M in the passes of csrc/kernels_rq.hip and takes
+    <g, M g> from one more application."""
+    solver, sm, _ = trio
+    gold = load_golden("rqmin_mass")
+
+    def mass(n):
+        return sp.diags([np.full(n - 1, 1.0 / 6.0), np.full(n, 4.0 / 6.0), np.full(n - 1, 1.0 / 6.0)], [-1, 0, 1], format="csr")
+
+    A, M = H(sm, 64), mass(64)
+    x, rho = solver.rqmin(A, gold["x0"], M, nu=4)
+    assert abs(rho - float(gold["rqmin_rho"])) < NORTH_STAR * abs(float(gold["rqmin_rho"])) and rel_err(x, gold["rqmin_x"]) < NORTH_STAR
+    x = gold["x0"].copy()
+    for i in range(2):
+        x, rho = solver.vcycle_rqmg(x, A, M)
+        assert abs(rho - gold["rqmg_rhos"][i]) < NORTH_STAR * abs(gold["rqmg_rhos"][i])
+    assert rel_err(x, gold["rqmg_x"]) < 1e-9
+    x, rho = solver.twogridrqmin(A, gold["x0"], M, repaired=True)
+    assert abs(rho - float(gold["twogrid_rho"])) < 1e-9 and rel_err(x, gold["twogrid_x"]) < 1e-8
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X = solver.vcycle_rqmg2(gold["X0"], H(sm, 32), mass(32), nmin=4)
+    A32, M32 = H(sm, 32), mass(32)
+    rq = [X[:, i] @ (A32 @ X[:, i]) / (X[:, i] @ (M32 @ X[:, i])) for i in range(2)]
+    assert np.allclose(rq, gold["rqmg2_nmin4_rq"], rtol=1e-9, atol=0)
+    for i in range(2):
+        ref_col = gold["rqmg2_nmin4_X"][:, i]
+        sign = np.sign(np.dot(X[:, i], ref_col))
+        assert rel_err(sign * X[:, i], ref_col) < 1e-8, i
+
+
 def test_repaired_rayleigh_quotient_variants(trio):
     """SURVEY §8 (f)4.  twogridrqmin(repaired=True) is the reference's own Rayleigh-quotient multigrid cut off after one
     coarsening: pinned by the reference's vcycle_rqmg(..., nmin=n/2) (fixture rqmin.npz: twogrid_*).  vcycle_rqmg2 with
