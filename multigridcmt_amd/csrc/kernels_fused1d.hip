@@ -134,9 +134,13 @@ __global__ void __launch_bounds__(256) k_fused1d(Args a) {
 
 }  // namespace fused1d
 
-// 1-D levels the fused passes cover (shorter ones are pure launch latency either way and keep the simple kernels)
+// 1-D levels the fused passes cover: every even length from 16 points on (a short level is one partly filled window — one
+// launch where the simple kernels take nu + 3; MGCMT_FUSED1D_MIN: A/B measurements)
+#ifndef MGCMT_FUSED1D_MIN
+#define MGCMT_FUSED1D_MIN 16
+#endif
 bool fused1d_supported(const KGrid& g, const KOp& op) {
-  return !g.coarsen_rows && g.nr == 1 && g.nc >= 256 && (g.nc & 1) == 0 && (op.tri_const || op.tri != nullptr);
+  return !g.coarsen_rows && g.nr == 1 && g.nc >= MGCMT_FUSED1D_MIN && (g.nc & 1) == 0 && (op.tri_const || op.tri != nullptr);
 }
 
 // stages' reach per side: one point per Jacobi sweep, two per red-black sweep, one for the correction, two for the restriction

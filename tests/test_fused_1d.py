@@ -57,7 +57,7 @@ def test_fused_1d_cycle_against_oracle_and_unfused(backend, n, kind, okind, omeg
     tol = {256: 1e-12, 1024: 5e-12, 4096: 5e-11}[n]
     for nu1, nu2, nuc in ((2, 2, 2), (4, 4, 4), (1, 3, 4), (5, 2, 3)):
         a, kinds = _cycle(n, 1, kind, omega, nu1, nu2, nuc, potential)
-        assert kinds[0] >= 4 and kinds[-1] == 0          # the fine level is on the fused passes, the 8-point level is not
+        assert kinds[0] >= 4 and kinds[-1] == 0 and kinds[-2] >= 4   # every level of >= 16 points is on the fused passes, the 8-point level is not
         b, _ = _cycle(n, 0, kind, omega, nu1, nu2, nuc, potential)
         assert rel_err(a, b) < tol, (nu1, nu2, nuc)
         y = st.vcycle(None, Y, n, 8, 0.3, okind, v0, f, nu1, nu2, nuc, omega)
