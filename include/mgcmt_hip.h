@@ -328,7 +328,11 @@ typedef enum mgcmt_option {
   MGCMT_OPT_LEX_CHAIN = 6,  /* default 1: the nu Gauss-Seidel sweeps of a smoothing step run chained in ONE launch of the scan pipeline
                                (sweep s + 1 follows sweep s a few rows behind); 0: one launch per sweep.  Same arithmetic, same bits */
   MGCMT_OPT_TAIL = 4        /* default 1: the 2-D levels of at most 32 x 32 points below a cycle's top level, coarse solve
-                               included, run as ONE launch out of LDS (needs MGCMT_OPT_FUSED; not with Gram-Schmidt) */
+                               included, run as ONE launch (needs MGCMT_OPT_FUSED; not with Gram-Schmidt): a dense product
+                               with the tail's matrix — the sub-cycle is linear in its right-hand side for fixed shift,
+                               smoother and sweep counts; the matrix is formed once per shift set by running the tail on
+                               the unit vectors —; 2: the LDS-resident launch of ~45 barrier-separated phases itself (the
+                               dense form's arithmetic in another summation order); 0: one launch per pass */
 } mgcmt_option;
 int mgcmt_plan_set_option(mgcmt_plan* plan, int option, int value);
 

@@ -138,7 +138,10 @@ __device__ void tail_smooth(const View& w, double* scratch, int kind, int nu, do
 
 __global__ void __launch_bounds__(kTailThreads) k_tail(TailArgs a) {
   __shared__ double sm[kTailLds];
-  const int q = blockIdx.x;
+  // unit_rhs: block b runs the tail on the unit vector e_b with vector `unit_q`'s shift and inverse — the columns of the
+  // tail's matrix (launch_tail_matrix)
+  const int q = a.unit_rhs ? a.unit_q : blockIdx.x;
+  const int out_q = blockIdx.x;
   const Layout L{a.g0, a.nlev, a.nterms};
   const double mu = a.shifts[q];
   // operator factors of every tail level
@@ -153,9 +156,9 @@ __global__ void __launch_bounds__(kTailThreads) k_tail(TailArgs a) {
   }
   {  // entry level: right-hand side from memory, zero start value (the error equation, MGCMTSolver.py:316)
     const int n = L.g0 * L.g0;
-    const double* f = a.f_in + q * a.vstride;
+    const double* f = a.unit_rhs ? nullptr : a.f_in + q * a.vstride;
     for (int p = threadIdx.x; p < n; p += kTailThreads) {
-      sm[L.f(0) + p] = f[p];
+      sm[L.f(0) + p] = f ? f[p] : (p == out_q ? 1.0 : 0.0);
       sm[L.v(0) + p] = 0.0;
     }
   }
@@ -248,8 +251,31 @@ __global__ void __launch_bounds__(kTailThreads) k_tail(TailArgs a) {
   }
   {
     const int n = L.g0 * L.g0;
-    double* v = a.v_out + q * a.vstride;
+    double* v = a.v_out + out_q * a.vstride;
     for (int p = threadIdx.x; p < n; p += kTailThreads) v[p] = sm[L.v(0) + p];
+  }
+}
+
+// v = T f with the tail's matrix stored by columns (column j = the tail applied to e_j: mt[j * n + i]): each block owns 16
+// outputs and reads their 128-byte pieces of all n columns — 64 column groups of 16 threads, the partial sums combined
+// through LDS in a fixed order.  n = g0^2 <= 1024, a multiple of 16.
+constexpr int kDenseOut = 16, kDenseGroups = 64;
+__global__ void __launch_bounds__(kDenseOut* kDenseGroups) k_tail_dense(int n, const double* __restrict__ mt, long mt_stride, const double* __restrict__ f_in,
+                                                                       double* __restrict__ v_out, long vstride) {
+  __shared__ double s_part[kDenseGroups][kDenseOut + 1];
+  const int q = blockIdx.y;
+  const int ii = threadIdx.x & (kDenseOut - 1), jj = threadIdx.x / kDenseOut;
+  const int i = blockIdx.x * kDenseOut + ii;
+  const double* m = mt + q * mt_stride;
+  const double* f = f_in + q * vstride;
+  double acc = 0.0;
+  for (int j = jj; j < n; j += kDenseGroups) acc = fma(m[(long)j * n + i], f[j], acc);
+  s_part[jj][ii] = acc;
+  __syncthreads();
+  if (jj == 0) {
+    double t = 0.0;
+    for (int g = 0; g < kDenseGroups; ++g) t += s_part[g][ii];
+    v_out[q * vstride + i] = t;
   }
 }
 
@@ -266,5 +292,23 @@ bool tail_fits(long g0, int nlev, int nterms) {
 }
 
 void launch_tail(hipStream_t s, const TailArgs& a, int k) { hipLaunchKernelGGL(k_tail, dim3((unsigned)k), dim3(kTailThreads), 0, s, a); }
+
+// columns of the tail's matrix for vector q's shift: mt[j * n + i] = (tail e_j)[i], n = g0^2
+void launch_tail_matrix(hipStream_t s, TailArgs a, int q, double* mt) {
+  const int n = a.g0 * a.g0;
+  a.unit_rhs = 1;
+  a.unit_q = q;
+  a.f_in = nullptr;
+  a.v_out = mt;
+  a.vstride = n;
+  hipLaunchKernelGGL(k_tail, dim3((unsigned)n), dim3(kTailThreads), 0, s, a);
+}
+
+bool tail_dense_fits(long g0) { return g0 * g0 <= 1024 && (g0 * g0) % kDenseOut == 0; }
+
+void launch_tail_dense(hipStream_t s, long g0, const double* mt, long mt_stride, const double* f_in, double* v_out, long vstride, int k) {
+  const int n = (int)(g0 * g0);
+  hipLaunchKernelGGL(k_tail_dense, dim3((unsigned)(n / kDenseOut), (unsigned)k), dim3(kDenseOut * kDenseGroups), 0, s, n, mt, mt_stride, f_in, v_out, vstride);
+}
 
 }  // namespace mgcmt

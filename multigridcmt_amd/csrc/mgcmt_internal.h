@@ -169,9 +169,15 @@ struct TailArgs {
   const double* shifts;
   double omega;
   int kind, nu;               // smoother and sweeps (pre and post) on every tail level
+  int unit_rhs, unit_q;       // launch_tail_matrix: block b runs on the unit vector e_b with vector unit_q's shift and inverse
 };
 bool tail_fits(long g0, int nlev, int nterms);
 void launch_tail(hipStream_t s, const TailArgs& a, int k);
+// The tail is linear in its right-hand side for fixed (shift, smoother, nu, omega): its matrix, formed once per shift set
+// by running the tail on the unit vectors, turns the ~45 barrier-separated phases into one dense product.
+bool tail_dense_fits(long g0);
+void launch_tail_matrix(hipStream_t s, TailArgs a, int q, double* mt);
+void launch_tail_dense(hipStream_t s, long g0, const double* mt, long mt_stride, const double* f_in, double* v_out, long vstride, int k);
 void launch_mgs_small(hipStream_t s, long n, double* a0, long stride, int k);
 // nb_in: partial sums per result in partials_in (0 = reduce_blocks(n), what the previous step left; 1 = already summed)
 void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out, int nb_in = 0);

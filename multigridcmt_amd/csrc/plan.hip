@@ -2,6 +2,7 @@
 // Host code only; every kernel it enqueues is in kernels_*.hip.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -658,11 +659,8 @@ int tail_level(const mgcmt_plan* p, int level, int kind, int nu_coarse, int gram
   return -1;
 }
 
-int run_tail(mgcmt_plan* p, int lt, int kind, int nu, double omega, int k, hipStream_t s) {
+TailArgs tail_args(mgcmt_plan* p, int lt, int kind, int nu, double omega) {
   const int last = (int)p->levels.size() - 1;
-  MG_TRY(ensure_coarse_ready(p, last, k, s));
-  MG_TRY(ensure_slot(p, lt, MGCMT_SLOT_V));
-  MG_TRY(ensure_slot(p, lt, MGCMT_SLOT_F));
   TailArgs a{};
   a.g0 = (int)p->levels[lt].gr;
   a.nlev = last - lt + 1;
@@ -686,8 +684,67 @@ int run_tail(mgcmt_plan* p, int lt, int kind, int nu, double omega, int k, hipSt
   a.omega = omega;
   a.kind = kind;
   a.nu = nu;
-  launch_tail(s, a, k);
+  return a;
+}
+
+// The tail's matrix per vector for the current shifts (allocated on first use, redone when the shifts or the cycle's
+// parameters change — like the coarsest level's factorisation, and like it never inside a graph capture: mgcmt_vcycle
+// calls this eagerly before a capture or a replay).
+int ensure_tail_matrix(mgcmt_plan* p, int lt, int kind, int nu, double omega, int k, hipStream_t s) {
+  mgcmt_plan::TailMatrix& T = p->tailmat;
+  const long n = (long)p->levels[lt].gr * p->levels[lt].gc;
+  bool same = T.valid && T.lt == lt && T.kind == kind && T.nu == nu && T.omega == omega && T.k >= k && T.n == n;
+  if (same)
+    for (int q = 0; q < k; ++q) same = same && T.shifts[q] == p->h_shifts[q];
+  if (same) return MGCMT_OK;
+  const int last = (int)p->levels.size() - 1;
+  MG_TRY(ensure_coarse_ready(p, last, k, s));
+  if (T.capacity < k || T.n != n) {
+    if (T.mt) {
+      MG_HIP(hipStreamSynchronize(s));
+      (void)hipFree(T.mt);
+      T.mt = nullptr;
+      p->graphs_invalidate();  // (cached graphs point at the old matrices)
+    }
+    MG_HIP(hipMalloc((void**)&T.mt, sizeof(double) * n * n * k));
+    T.capacity = k;
+  }
+  const TailArgs a = tail_args(p, lt, kind, nu, omega);
+  for (int q = 0; q < k; ++q) launch_tail_matrix(s, a, q, T.mt + (long)q * n * n);
+  T.n = n;
+  T.lt = lt;
+  T.kind = kind;
+  T.nu = nu;
+  T.omega = omega;
+  T.k = k;
+  T.shifts.assign(p->h_shifts.begin(), p->h_shifts.begin() + k);
+  T.valid = true;
   return post_launch();
+}
+
+bool tail_dense(const mgcmt_plan* p, int lt) { return p->use_tail_dense && lt > 0 && tail_dense_fits(p->levels[lt].gr); }
+
+int run_tail(mgcmt_plan* p, int lt, int kind, int nu, double omega, int k, hipStream_t s) {
+  const int last = (int)p->levels.size() - 1;
+  MG_TRY(ensure_coarse_ready(p, last, k, s));
+  MG_TRY(ensure_slot(p, lt, MGCMT_SLOT_V));
+  MG_TRY(ensure_slot(p, lt, MGCMT_SLOT_F));
+  if (tail_dense(p, lt)) {
+    MG_TRY(ensure_tail_matrix(p, lt, kind, nu, omega, k, s));
+    const long n = p->tailmat.n;
+    launch_tail_dense(s, p->levels[lt].gr, p->tailmat.mt, n * n, p->kvec(lt, MGCMT_SLOT_F).p, p->kvec(lt, MGCMT_SLOT_V).p,
+                      p->kvec(lt, MGCMT_SLOT_V).stride, k);
+    return post_launch();
+  }
+  launch_tail(s, tail_args(p, lt, kind, nu, omega), k);
+  return post_launch();
+}
+
+// what a cycle's tail needs ready outside a graph (the matrix of the dense form), for the cycle's parameters
+int ensure_tail_for_cycle(mgcmt_plan* p, int level, int nu_coarse, int kind, double omega, int k, int cycle_flags, hipStream_t s) {
+  const int lt = tail_level(p, level, kind, nu_coarse, cycle_flags & MGCMT_CYCLE_GRAM_SCHMIDT);
+  if (lt > 0 && tail_dense(p, lt)) return ensure_tail_matrix(p, lt, kind, nu_coarse, omega, k, s);
+  return MGCMT_OK;
 }
 
 int vcycle_body(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int kind, double omega, int k, int cycle_flags,
@@ -769,6 +826,10 @@ int mgcmt_plan_create(const mgcmt_plan_desc* d, mgcmt_plan** out) {
   p->lowest = d->lowest;
   p->has_mass = d->m_nterms > 0;
   p->h_shifts.assign(kMaxVec, 0.0);
+  {
+    const char* e = getenv("MGCMT_TAIL_DENSE");  // "0": the tail as the LDS-resident launch by default (the host-only test build:
+    p->use_tail_dense = !(e && e[0] == '0');     // emulating the 1024 workgroups that form the matrix takes minutes)
+  }
 
   int nlev = 1;
   for (int64_t s = d->g; s > d->lowest; s >>= 1) ++nlev;
@@ -857,6 +918,7 @@ int mgcmt_plan_destroy(mgcmt_plan* p) {
   if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
   if (p->d_rq) (void)hipFree(p->d_rq);
   if (p->d_rqstate) (void)hipFree(p->d_rqstate);
+  if (p->tailmat.mt) (void)hipFree(p->tailmat.mt);
   if (p->lex_carry) (void)hipFree(p->lex_carry);
   if (p->lex_sync) (void)hipFree(p->lex_sync);
   if (p->d_shifts) (void)hipFree(p->d_shifts);
@@ -1011,8 +1073,9 @@ int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int 
   }
   auto hit = p->graphs.find(key);
   if (hit != p->graphs.end()) {
-    // the coarsest-level factorisation depends on the shift VALUES; redo it eagerly when they changed
+    // the coarsest-level factorisation (and the tail's matrix) depend on the shift VALUES; redo them eagerly when they changed
     MG_TRY(ensure_coarse_factor(p, (int)p->levels.size() - 1, k, s));
+    MG_TRY(ensure_tail_for_cycle(p, level, nu_coarse, kind, omega, k, cycle_flags, s));
     MG_HIP(hipGraphLaunch(hit->second.exec, s));
     // a replayed cycle runs the wave pipeline too: the next synchronising call must look at its error word
     if (hit->second.lex_wave) p->lex_wave_used = true;
@@ -1026,6 +1089,7 @@ int mgcmt_vcycle(mgcmt_plan* p, int level, int nu1, int nu2, int nu_coarse, int 
   // the first cycle with these parameters runs eagerly: it allocates, factors and queries occupancies
   if (p->cycle_seen[params]++ == 0) return vcycle_body(p, level, nu1, nu2, nu_coarse, kind, omega, k, cycle_flags, s);
   MG_TRY(ensure_coarse_factor(p, (int)p->levels.size() - 1, k, s));
+  MG_TRY(ensure_tail_for_cycle(p, level, nu_coarse, kind, omega, k, cycle_flags, s));
   if (!p->capture_stream && hipStreamCreate(&p->capture_stream) != hipSuccess) {
     p->use_graph = false;
     (void)hipGetLastError();
@@ -1544,6 +1608,7 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
   }
   if (option == MGCMT_OPT_TAIL) {
     p->use_tail = value != 0;
+    p->use_tail_dense = value != 2;  // 1 (default): the tail as one dense product; 2: as the LDS-resident launch of ~45 phases
     p->graphs_invalidate();
     return MGCMT_OK;
   }

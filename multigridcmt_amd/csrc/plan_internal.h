@@ -74,6 +74,16 @@ struct mgcmt_plan {
   bool has_mass = false;
   bool use_fused = true;
   bool use_tail = true;   // levels of at most 32 x 32 points as one launch (kernels_tail.hip)
+  bool use_tail_dense = true;  // ... and that launch as ONE dense product with the tail's matrix (formed once per shift set)
+  struct TailMatrix {
+    double* mt = nullptr;   // [k][n * n]
+    int capacity = 0;       // vectors allocated
+    long n = 0;
+    int lt = -1, kind = -1, nu = -1, k = 0;
+    double omega = 0.0;
+    std::vector<double> shifts;
+    bool valid = false;
+  } tailmat;
   bool use_recompute = true;  // down-leg passes skip storing V', up-leg passes recompute it (fused_kernel.h)
   bool force_recompute = false;  // ... on every fused level, not only the bandwidth-bound ones (tests)
   // HIP-graph replay of whole cycles (mgcmt_vcycle): the launch sequence of a cycle is fixed by its

@@ -38,6 +38,7 @@ def bind_backend(kind):
         return
     plan.release_plans()
     if kind == "hip":
+        os.environ.pop("MGCMT_TAIL_DENSE", None)
         path = os.environ.get("MGCMT_TEST_LIBRARY", _lib.DEFAULT_LIBRARY)     # a tuning variant of the HIP library
         if not os.path.exists(path):
             pytest.fail("%s is not built — run __graft_entry__.build()" % path)
@@ -46,6 +47,9 @@ def bind_backend(kind):
             pytest.fail("no HIP device visible")
     else:
         import build_emu
+        # the dense form of the cycle's tail forms its matrix with 1024 workgroups of 1024 threads: minutes on the emulation.
+        # CPU tests run the LDS-resident tail unless a test asks for the dense form (tests/test_fused_kernels.py)
+        os.environ["MGCMT_TAIL_DENSE"] = "0"
         _lib.use_library(build_emu.build())
     _bound["kind"] = kind
 

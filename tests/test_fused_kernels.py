@@ -425,26 +425,34 @@ def test_potential_well_operator_three_terms(backend):
 
 @pytest.mark.parametrize("kind,omega", [(_lib.WJACOBI, 2. / 3.), (_lib.GS_MC, 1.0), (_lib.GS_MC, 1.25)])
 def test_cycle_tail_in_one_launch(backend, kind, omega):
-    """MGCMT_OPT_TAIL: the levels of at most 32 x 32 points (coarse solve included) as one LDS-resident launch give
-    the cycle of the level-by-level launches — several vectors with their own shifts, coarsest grids 8 and 2, a cycle
-    that starts right above the tail (64 x 64), and the three-term operator of a square well."""
+    """MGCMT_OPT_TAIL: the levels of at most 32 x 32 points (coarse solve included) as one launch — the dense product with
+    the tail's matrix (1, the default) and the LDS-resident launch of ~45 phases (2) — give the cycle of the
+    level-by-level launches (0): several vectors with their own shifts, coarsest grids 8 and 2, a cycle that starts right
+    above the tail (64 x 64), the three-term operator of a square well, and a change of shifts between two cycles (the
+    matrix is redone, also behind a replayed graph)."""
     from multigridcmt_amd.operators import potential_well_operator
     rng = np.random.RandomState(3)
     cases = [(laplacian_operator(256, "2d") * SCALE, 8, 3), (laplacian_operator(128, "2d") * SCALE, 2, 1),
              (laplacian_operator(64, "2d") * SCALE, 4, 2), (potential_well_operator(128, 25.0, (40, 90)), 8, 1)]
+    if backend == "emu":        # (forming the matrix of a 32 x 32 tail is 1024 emulated workgroups per vector: one case, one vector)
+        cases = [(laplacian_operator(64, "2d") * SCALE, 8, 1), (laplacian_operator(32, "2d") * SCALE, 4, 2)]
     for op, lowest, k in cases:
         n = op.g * op.g
         v0, f = rng.rand(k, n), rng.rand(k, n)
         outs = []
-        for tail in (1, 0):
+        for tail in (1, 2, 0):
             p = Plan(op, lowest, nvec=k)
             p.set_option(_lib.OPT_TAIL, tail)
             p.set_shifts(0.4 + 0.3 * np.arange(k))
             for q in range(k):
                 p.upload(0, _lib.SLOT_V, q, v0[q])
                 p.upload(0, _lib.SLOT_F, q, f[q])
+            for _ in range(3):
+                p.vcycle(2, 3, kind, omega=omega, k=k, nu_coarse=2)
+            p.set_shifts(0.1 + 0.2 * np.arange(k))          # other shifts: the same (possibly replayed) cycle, another matrix
             for _ in range(2):
                 p.vcycle(2, 3, kind, omega=omega, k=k, nu_coarse=2)
             outs.append(np.stack([p.download(0, _lib.SLOT_V, q) for q in range(k)]))
             p.close()
-        assert rel_err(outs[0], outs[1]) < 1e-12, (op.g, lowest, k)
+        assert rel_err(outs[0], outs[2]) < 1e-12, (op.g, lowest, k, "dense")
+        assert rel_err(outs[1], outs[2]) < 1e-12, (op.g, lowest, k, "phases")
