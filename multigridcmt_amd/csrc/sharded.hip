@@ -99,6 +99,54 @@ RcclApi* rccl() {
 
 }  // namespace
 
+namespace {
+
+// ---- which stream runs BESIDE the cycle's stream? -------------------------------------------------------------------
+// HIP deals a handful of hardware queues to the streams of a process round-robin; two streams on one queue run in
+// order, and then the exchange lane waits behind the interior launch it is meant to run beside (rocprofv3 traces of
+// round 3: 2.44 ms per emulated rank share with both lanes on one queue, 2.13 ms on two).  No API tells the queue of a
+// stream, so the communicator tries: a one-wave kernel that spins for a while on the cycle's stream, a trivial kernel on
+// the candidate — the candidate is on another queue if its kernel finishes while the spinner still runs.
+__global__ void k_spin(long ticks_100mhz, int* sink) {
+  int i = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const long t0 = (long)wall_clock64();
+  for (; i < 400000; ++i) {  // (bounded: every wave reaches the exit whatever the clock does)
+    if ((long)wall_clock64() - t0 > ticks_100mhz) break;
+    __builtin_amdgcn_s_sleep(16);
+  }
+#endif
+  if (threadIdx.x == 0) sink[0] = i;
+}
+__global__ void k_touch(int* sink) {
+  if (threadIdx.x == 0) sink[1] = 1;
+}
+
+// true when work on `cand` overtakes a running kernel on `main`
+bool runs_beside(hipStream_t main, hipStream_t cand, int* d_sink) {
+  hipEvent_t em = nullptr, ec = nullptr;
+  if (hipEventCreateWithFlags(&em, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ec, hipEventDisableTiming) != hipSuccess) {
+    if (em) (void)hipEventDestroy(em);
+    (void)hipGetLastError();
+    return false;
+  }
+  bool beside = false;
+  if (hipStreamSynchronize(main) == hipSuccess && hipStreamSynchronize(cand) == hipSuccess) {
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, main, 300000L /* 3 ms of the 100 MHz clock */, d_sink);
+    (void)hipEventRecord(em, main);
+    hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, cand, d_sink);
+    (void)hipEventRecord(ec, cand);
+    if (hipEventSynchronize(ec) == hipSuccess) beside = hipEventQuery(em) == hipErrorNotReady;
+    (void)hipStreamSynchronize(main);
+  }
+  (void)hipGetLastError();
+  (void)hipEventDestroy(em);
+  (void)hipEventDestroy(ec);
+  return beside;
+}
+
+}  // namespace
+
 namespace mgcmt {
 
 struct ShardComm {
@@ -115,6 +163,8 @@ struct ShardComm {
   bool overlap = true;    // RCCL transport only
   int split = 1;          // boundary rows first (both transports): 1 on strips of >= 2^22 points, 2 always (tests), 0 never
   bool self_ring = false; // one-rank self-test: the rank is its own neighbour above and below in every exchange
+  bool lane_checked = false;  // comm_stream has been tried against the cycle's stream (pick_exchange_stream)
+  hipStream_t lane_for = nullptr;
   int emulate_of = 0;     // > 1 on a ONE-rank communicator in self-ring mode: the plan is rank R's strip of an N-rank job (timing rehearsal)
   double* d_red = nullptr;  // [2 * kMaxVec] reduction results (inner products of the sharded Gram-Schmidt, mgcmt_allreduce_sum)
   std::vector<double> h_red;
@@ -233,6 +283,42 @@ int join_exchange(mgcmt_plan* p, hipStream_t s) {
     MG_HIP(hipStreamWaitEvent(s, c->ev_edges, 0));
     c->edges_pending = false;
   }
+  return MGCMT_OK;
+}
+
+// once per communicator and cycle stream: an exchange stream that runs beside `s` (a few candidates are created and tried;
+// RCCL transport with overlap only — the callback transports synchronise anyway)
+int pick_exchange_stream(mgcmt_plan* p, hipStream_t s) {
+  ShardComm* c = p->comm;
+  if (!c->nccl || !c->overlap || (c->lane_checked && c->lane_for == s)) return MGCMT_OK;
+  c->lane_checked = true;
+  c->lane_for = s;
+  const char* e = getenv("MGCMT_COMM_LANE_CHECK");  // "0": keep the stream the communicator was created with
+  if (e && e[0] == '0') return MGCMT_OK;
+  int* d_sink = nullptr;
+  if (hipMalloc((void**)&d_sink, 2 * sizeof(int)) != hipSuccess) {
+    (void)hipGetLastError();
+    return MGCMT_OK;
+  }
+  MG_HIP(hipStreamSynchronize(c->comm_stream));
+  if (!runs_beside(s, c->comm_stream, d_sink)) {
+    std::vector<hipStream_t> tried;
+    for (int t = 0; t < 6; ++t) {
+      hipStream_t cand = nullptr;
+      if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        break;
+      }
+      if (runs_beside(s, cand, d_sink)) {
+        (void)hipStreamDestroy(c->comm_stream);
+        c->comm_stream = cand;
+        break;
+      }
+      tried.push_back(cand);  // (kept alive until the search ends: a destroyed stream's queue slot would be dealt again)
+    }
+    for (hipStream_t t : tried) (void)hipStreamDestroy(t);
+  }
+  (void)hipFree(d_sink);
   return MGCMT_OK;
 }
 
@@ -571,6 +657,7 @@ int mgcmt_sharded_vcycle(mgcmt_plan* p, mgcmt_plan* coarse, int nu1, int nu2, in
   if (ls < 1) return fail(MGCMT_ERR_INVALID, "strip plan has no level below the finest one");
   ShardComm* c = p->comm;
   hipStream_t s = (hipStream_t)stream;
+  MG_TRY(pick_exchange_stream(p, s));
   for (int l = 0; l <= ls; ++l) {
     MG_TRY(ensure_slot(p, l, MGCMT_SLOT_V));
     MG_TRY(ensure_slot(p, l, MGCMT_SLOT_F));

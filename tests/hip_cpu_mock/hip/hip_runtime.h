@@ -154,3 +154,7 @@ hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipEventDestroy(hipEvent_t e);
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }  // everything is synchronous here
+enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
+enum { hipErrorNotReady = 600 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
