@@ -16,6 +16,8 @@
 // tridiagonal whose last diagonal entry may differ (the one-sided P / R of the reference leave exactly that) — four
 // scalars — or a general tridiagonal (a potential on the diagonal, 1DPotMatrixVcycle.py:16) read from the level's
 // combined factor array, 48 B per point more.  Colours of the multicolour smoother in 1-D: odd points, then even ones.
+#include <cstdlib>
+
 #include "fused_kernel.h"
 
 namespace mgcmt {
@@ -184,8 +186,12 @@ void launch_fused1d(hipStream_t s, KGrid g, KOp op, KVec vin, KVec f, KVec vout,
   a.halo = need <= 8 ? 8 : (need <= 16 ? 16 : (need <= 24 ? 24 : 32));
   const long wout = 128 - 2 * a.halo;
   a.nwindows = (g.nc + wout - 1) / wout;
-  // one wave per window up to a few rounds of the chip, then grid-stride trips
-  const long max_waves = 256L * 32 * 4;
+  // one wave per window up to a few rounds of the chip, then grid-stride trips (MGCMT_FUSED1D_MAX_WAVES: A/B measurements)
+  static const long max_waves = [] {
+    const char* e = getenv("MGCMT_FUSED1D_MAX_WAVES");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? v : 256L * 32 * 4;
+  }();
   long waves = a.nwindows < max_waves ? a.nwindows : max_waves;
   const unsigned blocks = (unsigned)((waves + 3) / 4);
   a.wave_stride = (long)blocks * 4;
