@@ -60,16 +60,16 @@ def _worker(rank, world, port, g, kind, omega, nu, out_dir, force_recompute, opn
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,force_recompute", [(2, False), (4, False), (2, True)])
+@pytest.mark.parametrize("world,force_recompute,g", [(2, False, 512), (4, False, 1024), (2, True, 512)])
 @pytest.mark.parametrize("kind_name", ["wjacobi", "rb"])
-def test_sharded_cycle_equals_single_plan(tmp_path, world, kind_name, force_recompute):
+def test_sharded_cycle_equals_single_plan(tmp_path, world, kind_name, force_recompute, g):
     import torch.multiprocessing as mp
     from conftest import bind_backend
     bind_backend("emu")
     from multigridcmt_amd import _lib
     from multigridcmt_amd.operators import laplacian_operator
     from multigridcmt_amd.plan import Plan
-    g, nu = 1024, 2
+    nu = 2
     kind, omega = (_lib.WJACOBI, 2. / 3.) if kind_name == "wjacobi" else (_lib.GS_MC, 1.0)
     mp.spawn(_worker, args=(world, _free_port(), g, kind, omega, nu, str(tmp_path), force_recompute), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / ("part%d.npy" % r)) for r in range(world)])
