@@ -14,7 +14,7 @@ p.set_shifts([0.0])
 p.fill(0, _lib.SLOT_F, 0, 1.0); p.fill(0, _lib.SLOT_V, 0, 0.0)
 n = float(g) * g
 for kind, name, om in ((_lib.WJACOBI, "wjacobi", 2 / 3), (_lib.GS_MC, "rb", 1.0)):
-    for rows in (0, 32, 64, 128, 256, 1024):
+    for rows in [int(x) for x in os.environ.get("SWEEP_ROWS", "0,32,64,128,256,1024").split(",")]:
         p.set_option(_lib.OPT_FUSED_ROWS, rows)
         rec = {"smoother": name, "rows": rows}
         for label, mode, bpp in (("down", 2 | 8, 18), ("up", 1 | 32, 26), ("plain", 0, 24)):
