@@ -226,6 +226,34 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2(KGrid g, KOp A, KOp Mo,
   block_partials<3>(acc, s_part, partials, nblocks, (int)(blockIdx.y * gridDim.x + blockIdx.x));
 }
 
+// <g, M g> for M != I without storing M g: the march over g alone, result 3 of the pass-2 partial sums (same grid)
+template <int MM>
+__global__ void __launch_bounds__(kRqThreads) k_rq_gmg(KGrid g, KOp Mo, const double* __restrict__ gv, int rows, double* __restrict__ partials, int nblocks) {
+  __shared__ double s_part[1][kRqThreads / 64];
+  const long j = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  const long nc = g.nc;
+  const long i0 = (long)blockIdx.y * rows;
+  const long i1 = i0 + rows < g.nr ? i0 + rows : g.nr;
+  double acc[1] = {0.0};
+  if (j < nc) {
+    const bool hw = j > 0, he = j + 2 < nc;
+    const long jw = hw ? j - 1 : j, je = he ? j + 2 : j + 1;
+    Fac<MM> fm;
+    load_fac<MM>(Mo, j, fm);
+    Row4 gn = load4(gv, nullptr, 1.0, 0.0, i0 - 1, nc, j, jw, je, hw, he), gc = load4(gv, nullptr, 1.0, 0.0, i0, nc, j, jw, je, hw, he);
+#pragma unroll 2
+    for (long i = i0; i < i1; ++i) {
+      const Row4 gs = load4(gv, nullptr, 1.0, 0.0, i + 1, nc, j, jw, je, hw, he);
+      double ma, mb;
+      apply2<MM>(Mo, fm, i, gn, gc, gs, ma, mb);
+      acc[0] = fma(gc.b, mb, fma(gc.a, ma, acc[0]));
+      gn = gc;
+      gc = gs;
+    }
+  }
+  block_partials<1>(acc, s_part, partials + 3L * nblocks, nblocks, (int)(blockIdx.y * gridDim.x + blockIdx.x));
+}
+
 // ---- one thread per point (1-D levels, odd shapes): the same arithmetic through direct neighbour loads ---------------
 
 // (Op v)(i, j) with v = cu u + cw w (u alone when w == nullptr); identity: v(i, j)
@@ -384,13 +412,13 @@ __global__ void __launch_bounds__(64 * kRqSums) k_rq_scalars1(const double* __re
 __global__ void __launch_bounds__(256) k_rq_scalars2(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int m_identity,
                                                            int init) {
   __shared__ double s[4];
-  reduce_results(partials, nblocks, 3, s);
+  reduce_results(partials, nblocks, m_identity == 2 ? 4 : 3, s);  // m_identity == 2: <g, M g> is result 3 of the partial sums (k_rq_gmg)
   if (threadIdx.x != 0) return;
   state[kXAXn] = s[0];
   state[kXMXn] = s[1];
   state[kGG] = s[2];
   state[kRho] = s[0] / s[1];
-  const double gmg = m_identity ? s[2] : state[kGMG];
+  const double gmg = m_identity == 1 ? s[2] : (m_identity == 2 ? s[3] : state[kGMG]);
   // the first step takes p = -g (:29-30): beta = 0; afterwards <g,Mg> / <g_old,Mg_old>
   const double prev = state[kGMGprev];
   state[kBeta] = (init == 1 || !(prev != 0.0)) ? 0.0 : gmg / prev;  // (a previous gradient of exact zeros: restart from -g)
@@ -491,6 +519,21 @@ int launch_rq_pass2(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const
     hipLaunchKernelGGL(k_rq_pass2_point, dim3((unsigned)blocks), dim3(kRqThreads), 0, s, g, A, Mo, m_identity, x, p, xnew, gout, state, init, partials, nblocks);
   }
   return nblocks;
+}
+
+// <g, M g> into result 3 of pass 2's partial sums (march levels with a one-term M): true when launched — launch_rq_scalars2
+// then takes m_identity = 2; false: the caller computes it (application + dot product) into state[rq_word_gmg()]
+bool launch_rq_gmg(hipStream_t s, KGrid g, KOp Mo, const double* gv, double* partials, int nblocks) {
+  if (!(g.coarsen_rows && g.nr >= 2 && g.nc >= 2 && (g.nc & 1) == 0 && (((uintptr_t)gv) & 15) == 0 && Mo.nterms == 1)) return false;
+  const dim3 b(g.nc >= 512 ? kRqThreads : 64, 1, 1);
+  const unsigned gx = (unsigned)((g.nc / 2 + b.x - 1) / b.x);
+  long rows = 32;
+  while ((long)gx * ((g.nr + rows - 1) / rows) > 4096) rows *= 2;
+  while (rows > 2 && (long)gx * ((g.nr + rows - 1) / rows) < 2048) rows /= 2;
+  const dim3 grid(gx, (unsigned)((g.nr + rows - 1) / rows), 1);
+  if ((int)(grid.x * grid.y) != nblocks) return false;  // (pass 2 took the point form: another block count)
+  hipLaunchKernelGGL((k_rq_gmg<1>), grid, b, 0, s, g, Mo, gv, (int)rows, partials, nblocks);
+  return true;
 }
 
 void launch_rq_scalars2(hipStream_t s, const double* partials, int nblocks, double* state, int m_identity, int init) {
