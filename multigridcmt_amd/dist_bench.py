@@ -205,8 +205,11 @@ def run(args, backend="nccl", on_gpu=True, cpu_baseline=None):
     reps = 10
     fuse = max(sp.plan.fused_max_sweeps(0, kind), 1)
     launches = -(-args.nu // fuse)
-    ms = sp.plan.time_smoother(0, kind, args.nu, omega, reps)
-    launch_s = ms * 1e-3 / (reps * launches)
+    try:                                                         # (local to the rank: a failure here must not cost the line)
+        ms = sp.plan.time_smoother(0, kind, args.nu, omega, reps)
+        launch_s = ms * 1e-3 / (reps * launches)
+    except Exception:                                            # noqa: BLE001
+        launch_s = float("nan")
     sp.invalidate(_lib.SLOT_V)
     n = float(g) * g
     if rank == 0:
