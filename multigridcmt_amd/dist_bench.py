@@ -209,7 +209,7 @@ def run(args, backend="nccl", on_gpu=True, cpu_baseline=None):
         ms = sp.plan.time_smoother(0, kind, args.nu, omega, reps)
         launch_s = ms * 1e-3 / (reps * launches)
     except Exception:                                            # noqa: BLE001
-        launch_s = float("nan")
+        launch_s = None
     sp.invalidate(_lib.SLOT_V)
     n = float(g) * g
     if rank == 0:
@@ -238,9 +238,9 @@ def run(args, backend="nccl", on_gpu=True, cpu_baseline=None):
             "checksum_after_%d_cycles" % CHECK_CYCLES: checksum,
             "roofline": {"bound": "hbm", "kernel": "fused fine-level pass on this rank's strip (%d x %d points), %d %s sweep(s) per launch"
                                                    % (sp.plan.shapes[0][0], g, min(fuse, args.nu), args.smoother),
-                         "achieved": n_strip * 24.0 / launch_s / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": n_strip * 24.0 / launch_s / 1e9 / 8000.0, "bytes_per_launch": n_strip * 24.0,
-                         "avg_launch_ms": launch_s * 1e3, "traffic": None, "rank": 0},
+                         "achieved": n_strip * 24.0 / launch_s / 1e9 if launch_s else None, "peak": 8000.0, "unit": "GB/s",
+                         "frac": n_strip * 24.0 / launch_s / 1e9 / 8000.0 if launch_s else None, "bytes_per_launch": n_strip * 24.0,
+                         "avg_launch_ms": launch_s * 1e3 if launch_s else None, "traffic": None, "rank": 0},
         }
         if parity is not None:
             out["parity_vs_single_plan"] = parity
