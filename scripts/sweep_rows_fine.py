@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 from multigridcmt_amd import _lib
 from multigridcmt_amd.operators import laplacian_operator
 from multigridcmt_amd.plan import Plan
+if os.environ.get("MGCMT_LIBRARY"):                      # a compile-time variant of the library (scripts/build_variants.sh)
+    _lib.use_library(os.environ["MGCMT_LIBRARY"])
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 p = Plan(laplacian_operator(g, "2d") * (-1 / np.pi ** 2), 8, nvec=1)
 p.set_shifts([0.0])
