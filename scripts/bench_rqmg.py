@@ -31,7 +31,7 @@ for _ in range(n):
     rhos.append(S._rqmg_levels(plan, 0, nu, nu)[1])
 plan.sync()
 ms = (time.perf_counter() - t0) / n * 1e3
-# one rqmin call alone on the finest level (nu steps + the initial pair): bytes = (nu + 1) * 64 B per point
+# one rqmin call alone on the finest level: nu steps of 64 B per point + the initial pair (x read twice, g written: 24 B)
 plan.sync()
 t0 = time.perf_counter()
 for _ in range(n):
@@ -41,4 +41,4 @@ ms_fine = (time.perf_counter() - t0) / n * 1e3
 pts = float(g) * g
 print(json.dumps({"workload": "vcycle_rqmg on the %d^2 square well, nu1 = nu2 = %d, nmin 8, iterate resident" % (g, nu), "ms_per_cycle": ms,
                   "rayleigh_quotients": rhos, "rqmin_fine_level_ms": ms_fine,
-                  "rqmin_fine_level_GBs_at_64B_per_point_and_step": (nu + 1) * 64.0 * pts / (ms_fine * 1e-3) / 1e9}))
+                  "rqmin_fine_level_GBs_of_compulsory_bytes": (nu * 64.0 + 24.0) * pts / (ms_fine * 1e-3) / 1e9}))
