@@ -36,22 +36,37 @@ struct Row4 {
   double w, a, b, e;  // columns j-1, j, j+1, j+2 (zero outside the grid)
 };
 
+// operator forms: M = 0 the identity; 1 .. 4 that many Kronecker terms with general tridiagonal factors; kFive + ND a
+// constant 5-point operator plus ND (0 .. 2) product potentials p_m(i) q_m(j) on the diagonal (KOp.five_point /
+// five_diag: the finest level of a scaled Laplacian or of a square-well Hamiltonian — six multiply-adds per point instead
+// of the 36 + of three general terms, and two column values in registers instead of 18)
+constexpr int kFive = 5;
 template <int M>
 struct Fac {
-  double yl[M > 0 ? M : 1][2], yd[M > 0 ? M : 1][2], yu[M > 0 ? M : 1][2];
+  static constexpr int T = (M >= 1 && M <= 4) ? M : 1;
+  double yl[T][2], yd[T][2], yu[T][2];
+  double qa[2], qb[2];  // kFive + ND: q_m at the two columns
 };
 
 template <int M>
 __device__ __forceinline__ void load_fac(const KOp& op, long j, Fac<M>& f) {
+  if constexpr (M >= kFive) {
 #pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const double* Y = op.Y[m] + j + c;
-      f.yl[m][c] = Y[0];
-      f.yd[m][c] = Y[op.ldy];
-      f.yu[m][c] = Y[2 * op.ldy];
+    for (int m = 0; m < M - kFive; ++m) {
+      f.qa[m] = op.dY[m][j];
+      f.qb[m] = op.dY[m][j + 1];
     }
+  } else {
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const double* Y = op.Y[m] + j + c;
+        f.yl[m][c] = Y[0];
+        f.yd[m][c] = Y[op.ldy];
+        f.yu[m][c] = Y[2 * op.ldy];
+      }
+  }
 }
 
 // (Op v) at (i, j) and (i, j+1) from the rows above / at / below; M == 0: the identity.  eval_point's terms.
@@ -62,11 +77,24 @@ __device__ __forceinline__ void apply2(const KOp& op, const Fac<M>& f, long i, c
     rb = c.b;
     return;
   }
+  if constexpr (M >= kFive) {
+    double da = op.c0, db = op.c0;
+#pragma unroll
+    for (int m = 0; m < M - kFive; ++m) {
+      const double pm = op.dX[m][i];
+      da = fma(pm, f.qa[m], da);
+      db = fma(pm, f.qb[m], db);
+    }
+    ra = fma(da, c.a, fma(op.cn, n.a + s.a, op.cw * (c.w + c.b)));
+    rb = fma(db, c.b, fma(op.cn, n.b + s.b, op.cw * (c.a + c.e)));
+    return;
+  }
   // (explicit multiply-adds: the library is built with -ffp-contract=off, and on the Galerkin levels — every term a full
   // 9-point stencil, M too — these passes are bound by the vector ALUs, not by memory)
   double offa = 0.0, offb = 0.0, da = 0.0, db = 0.0;
+  constexpr int TERMS = M < kFive ? M : 0;
 #pragma unroll
-  for (int m = 0; m < M; ++m) {
+  for (int m = 0; m < TERMS; ++m) {
     const double* X = op.X[m] + i;
     const double xl = X[0], xd = X[op.ldx], xu = X[2 * op.ldx];
     {
@@ -444,6 +472,13 @@ void launch_pass2_ma(hipStream_t s, int mm, dim3 grid, dim3 block, KGrid g, cons
   else hipLaunchKernelGGL((k_rq_pass2<MA, 1>), grid, block, 0, s, g, A, Mo, x, p, xnew, gout, state, init, rows, partials, nblocks);
 }
 
+// which instantiation serves A (see Fac): the 5-point forms where the plan recognised one, the general terms otherwise
+int operator_form(const KOp& A) {
+  if (A.five_point && A.cn != 0.0) return kFive;
+  if (A.five_diag && A.ndiag >= 1 && A.ndiag <= 2) return kFive + A.ndiag;
+  return A.nterms < 1 ? 1 : (A.nterms > 4 ? 4 : A.nterms);
+}
+
 bool march_ok(const KGrid& g, const KOp& A, const KOp& Mo, int m_identity, const double* a, const double* b, const double* c, const double* d,
               const double* e) {
   const uintptr_t all = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e;
@@ -473,11 +508,14 @@ void launch_rq_pass1(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, cons
     const dim3 grid(gx, (unsigned)((g.nr + rows - 1) / rows), 1);
     nblocks = (int)(grid.x * grid.y);
     const int mm = m_identity ? 0 : 1;
-    switch (A.nterms) {
+    switch (operator_form(A)) {
       case 1: launch_pass1_ma<1>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
       case 2: launch_pass1_ma<2>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
       case 3: launch_pass1_ma<3>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
-      default: launch_pass1_ma<4>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      case 4: launch_pass1_ma<4>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      case kFive: launch_pass1_ma<kFive>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      case kFive + 1: launch_pass1_ma<kFive + 1>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      default: launch_pass1_ma<kFive + 2>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
     }
   } else {
     const long n = g.nr * g.nc;
@@ -505,11 +543,14 @@ int launch_rq_pass2(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const
     const dim3 grid(gx, (unsigned)((g.nr + rows - 1) / rows), 1);
     nblocks = (int)(grid.x * grid.y);
     const int mm = m_identity ? 0 : 1;
-    switch (A.nterms) {
+    switch (operator_form(A)) {
       case 1: launch_pass2_ma<1>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
       case 2: launch_pass2_ma<2>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
       case 3: launch_pass2_ma<3>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
-      default: launch_pass2_ma<4>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      case 4: launch_pass2_ma<4>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      case kFive: launch_pass2_ma<kFive>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      case kFive + 1: launch_pass2_ma<kFive + 1>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      default: launch_pass2_ma<kFive + 2>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
     }
   } else {
     const long n = g.nr * g.nc;
