@@ -163,7 +163,10 @@ __device__ __forceinline__ double from_lane_above(double v) {  // lane + 1's val
 #endif
 }
 
-// v = cu * u + cw * w at columns j-1 .. j+2 of row i (u alone when w == nullptr).  Every lane loads its own two columns
+// v = cu * u + cw * w at columns j-1 .. j+2 of row i (u alone when w == nullptr).  (The neighbour columns by wave-wide DPP
+// shifts instead of two more loads per row and vector — only the wave's first and last lane loading theirs — was measured
+// in round 3: 8.82 against 8.27 ms per 8192^2 vcycle_rqmg cycle; the loads from L1 are cheaper than the divergent edge
+// lanes and the loop the compiler then no longer unrolls.).  Every lane loads its own two columns
 // (16 bytes); the columns j-1 and j+2 are the neighbouring lanes' — a wave-wide shift — and only the wave's first and last
 // lane load theirs from memory (three loads per row and vector before: the neighbour columns came from L1, but every
 // load is an instruction and an L1 transaction).
