@@ -141,58 +141,29 @@ __device__ __forceinline__ void block_partials(const double* acc, double (*s_par
 
 // ---- row march (2-D, even sizes) ------------------------------------------------------------------------------
 
-// value of the neighbouring lane (wave-wide DPP shift: no memory, no LDS; lanes 0 / 63 get a zero and load their own)
-__device__ __forceinline__ double from_lane_below(double v) {  // lane - 1's value
-#if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x138, 0xf, 0xf, true);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x138, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-#else
-  return __shfl_up(v, 1);
-#endif
-}
-__device__ __forceinline__ double from_lane_above(double v) {  // lane + 1's value
-#if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x130, 0xf, 0xf, true);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x130, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-#else
-  return __shfl_down(v, 1);
-#endif
-}
-
 // v = cu * u + cw * w at columns j-1 .. j+2 of row i (u alone when w == nullptr).  (The neighbour columns by wave-wide DPP
 // shifts instead of two more loads per row and vector — only the wave's first and last lane loading theirs — was measured
 // in round 3: 8.82 against 8.27 ms per 8192^2 vcycle_rqmg cycle; the loads from L1 are cheaper than the divergent edge
-// lanes and the loop the compiler then no longer unrolls.).  Every lane loads its own two columns
-// (16 bytes); the columns j-1 and j+2 are the neighbouring lanes' — a wave-wide shift — and only the wave's first and last
-// lane load theirs from memory (three loads per row and vector before: the neighbour columns came from L1, but every
-// load is an instruction and an L1 transaction).
+// lanes and the loop the compiler then no longer unrolls.)
 __device__ __forceinline__ Row4 load4(const double* __restrict__ u, const double* __restrict__ w, double cu, double cw, long i, long nc, long j, long jw,
                                       long je, bool hw, bool he) {
   const double2 c = *reinterpret_cast<const double2*>(u + i * nc + j);
-  double a = c.x, b = c.y;
+  Row4 r{hw ? u[i * nc + jw] : 0.0, c.x, c.y, he ? u[i * nc + je] : 0.0};
+  if (!w && cu != 1.0) {
+    r.w *= cu;
+    r.a *= cu;
+    r.b *= cu;
+    r.e *= cu;
+  }
   if (w) {
     const double2 d = *reinterpret_cast<const double2*>(w + i * nc + j);
-    a = fma(cw, d.x, cu * a);
-    b = fma(cw, d.y, cu * b);
-  } else if (cu != 1.0) {
-    a *= cu;
-    b *= cu;
+    const double dw = hw ? w[i * nc + jw] : 0.0, de = he ? w[i * nc + je] : 0.0;
+    r.w = fma(cw, dw, cu * r.w);
+    r.a = fma(cw, d.x, cu * r.a);
+    r.b = fma(cw, d.y, cu * r.b);
+    r.e = fma(cw, de, cu * r.e);
   }
-  double wv = from_lane_below(b), ev = from_lane_above(a);
-  const int lane = threadIdx.x & 63;
-  if (lane == 0 && hw) {
-    wv = u[i * nc + jw];
-    wv = w ? fma(cw, w[i * nc + jw], cu * wv) : (cu != 1.0 ? cu * wv : wv);
-  }
-  if (lane == 63 && he) {
-    ev = u[i * nc + je];
-    ev = w ? fma(cw, w[i * nc + je], cu * ev) : (cu != 1.0 ? cu * ev : ev);
-  }
-  return Row4{hw ? wv : 0.0, a, b, he ? ev : 0.0};
+  return r;
 }
 
 template <int MA, int MM>
@@ -220,6 +191,7 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass1(KGrid g, KOp A, KOp Mo,
     auto loadp = [&](long i) { return init == 1 ? zero : load4(gv, po, -1.0, beta, i, nc, j, jw, je, hw, he); };
     Row4 xn = load4(x, nullptr, 1.0, 0.0, i0 - 1, nc, j, jw, je, hw, he), xc = load4(x, nullptr, 1.0, 0.0, i0, nc, j, jw, je, hw, he);
     Row4 pn = loadp(i0 - 1), pc = loadp(i0);
+#pragma unroll 2
     for (long i = i0; i < i1; ++i) {
       const Row4 xs = load4(x, nullptr, 1.0, 0.0, i + 1, nc, j, jw, je, hw, he);
       const Row4 ps = loadp(i + 1);
@@ -266,6 +238,7 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2(KGrid g, KOp A, KOp Mo,
     load_fac<MM>(Mo, j, fm);
     const double* pp = init == 1 ? nullptr : p;
     Row4 xn = load4(x, pp, 1.0, delta, i0 - 1, nc, j, jw, je, hw, he), xc = load4(x, pp, 1.0, delta, i0, nc, j, jw, je, hw, he);
+#pragma unroll 2
     for (long i = i0; i < i1; ++i) {
       const Row4 xs = load4(x, pp, 1.0, delta, i + 1, nc, j, jw, je, hw, he);
       double axa, axb, mxa, mxb;
@@ -299,6 +272,7 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_gmg(KGrid g, KOp Mo, const do
     Fac<MM> fm;
     load_fac<MM>(Mo, j, fm);
     Row4 gn = load4(gv, nullptr, 1.0, 0.0, i0 - 1, nc, j, jw, je, hw, he), gc = load4(gv, nullptr, 1.0, 0.0, i0, nc, j, jw, je, hw, he);
+#pragma unroll 2
     for (long i = i0; i < i1; ++i) {
       const Row4 gs = load4(gv, nullptr, 1.0, 0.0, i + 1, nc, j, jw, je, hw, he);
       double ma, mb;
