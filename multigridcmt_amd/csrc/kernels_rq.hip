@@ -385,11 +385,8 @@ __device__ __forceinline__ void reduce_results(const double* __restrict__ partia
 // (:49-50), and rho of x + delta p by bilinearity (what pass 2 needs before it has formed x').  init: delta = 0.
 // robust (the repaired variants, solver.py): a degenerate pencil ends the minimisation on this level (delta = 0 from
 // here on) instead of producing infinities.
-__global__ void __launch_bounds__(64 * kRqSums) k_rq_scalars1(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int init,
-                                                           int robust) {
-  __shared__ double s[kRqSums];
-  reduce_results(partials, nblocks, kRqSums, s);
-  if (threadIdx.x != 0) return;
+// (one thread) the step's scalars from the eight sums s
+__device__ void rq_step_scalars(const double* s, double* __restrict__ state, int init, int robust) {
   for (int q = 0; q < kRqSums; ++q) state[q] = s[q];
   const double r00 = s[kS_xAx], r01 = s[kS_xAp], r10 = s[kS_pAx], r11 = s[kS_pAp];
   const double m00 = s[kS_xMx], m01 = s[kS_xMp], m10 = s[kS_pMx], m11 = s[kS_pMp];
@@ -439,22 +436,135 @@ __global__ void __launch_bounds__(64 * kRqSums) k_rq_scalars1(const double* __re
   state[kRhoLin] = fabs(rl) <= 1.7e308 ? rl : r00 / m00;
 }
 
-// after pass 2 (and, with M != I, after <g, M g> has been put into state[kGMG] by a dot product): rho (:53), beta (:31)
-__global__ void __launch_bounds__(256) k_rq_scalars2(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int m_identity,
-                                                           int init) {
-  __shared__ double s[4];
-  reduce_results(partials, nblocks, m_identity == 2 ? 4 : 3, s);  // m_identity == 2: <g, M g> is result 3 of the partial sums (k_rq_gmg)
+
+__global__ void __launch_bounds__(64 * kRqSums) k_rq_scalars1(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int init,
+                                                           int robust) {
+  __shared__ double s[kRqSums];
+  reduce_results(partials, nblocks, kRqSums, s);
   if (threadIdx.x != 0) return;
+  rq_step_scalars(s, state, init, robust);
+}
+
+// after pass 2 (and, with M != I, after <g, M g> has been put into state[kGMG] by a dot product): rho (:53), beta (:31)
+// (one thread) rho and the next step's beta from <x',Ax'>, <x',Mx'>, <g',g'> (s[0..2]) and <g',Mg'> (gmg_in unless M = I)
+__device__ void rq_gradient_scalars(const double* s, double gmg_in, double* __restrict__ state, int m_identity, int init) {
   state[kXAXn] = s[0];
   state[kXMXn] = s[1];
   state[kGG] = s[2];
   state[kRho] = s[0] / s[1];
-  const double gmg = m_identity == 1 ? s[2] : (m_identity == 2 ? s[3] : state[kGMG]);
+  const double gmg = m_identity == 1 ? s[2] : gmg_in;
   // the first step takes p = -g (:29-30): beta = 0; afterwards <g,Mg> / <g_old,Mg_old>
   const double prev = state[kGMGprev];
   state[kBeta] = (init == 1 || !(prev != 0.0)) ? 0.0 : gmg / prev;  // (a previous gradient of exact zeros: restart from -g)
   state[kGMGprev] = gmg;
   state[kGMG] = gmg;
+}
+
+
+__global__ void __launch_bounds__(256) k_rq_scalars2(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int m_identity,
+                                                           int init) {
+  __shared__ double s[4];
+  reduce_results(partials, nblocks, m_identity == 2 ? 4 : 3, s);  // m_identity == 2: <g, M g> is result 3 of the partial sums (k_rq_gmg)
+  if (threadIdx.x != 0) return;
+  rq_gradient_scalars(s, m_identity == 2 ? s[3] : state[kGMG], state, m_identity, init);
+}
+
+// ---- a whole rqmin call in ONE launch (levels of at most kRqSmallMax points) -------------------------------------------
+// The levels below the top of an RQMG cycle, and every level of the reference's own 1-D problems (RQMin.py: n = 64), are
+// a few thousand points: there the 3 - 5 launches per step are all the time there is (~6 us each, 12 + per cycle level).
+// One workgroup holds the level (up to four points per thread) and runs initial pair + nu steps start to end: vectors
+// updated in place in global memory (they stay in the CU's L1 / L2), the sums reduced in LDS, the scalars of both passes
+// computed by thread 0 into an LDS copy of the state block — the same arithmetic as the pass kernels, block barriers
+// where those have kernel boundaries.
+constexpr int kRqSmallThreads = 1024;
+constexpr int kRqSmallMax = 4 * kRqSmallThreads;
+
+template <int NQ>
+__device__ __forceinline__ void small_reduce(const double* acc, double (*s_part)[kRqSmallThreads / 64], double* s_sum) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double t = acc[q];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
+    if (lane == 0) s_part[q][wave] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NQ) {
+    double t = 0.0;
+    for (int k = 0; k < kRqSmallThreads / 64; ++k) t += s_part[threadIdx.x][k];
+    s_sum[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(kRqSmallThreads) k_rq_small(KGrid g, KOp A, KOp Mo, int m_identity, double* x, double* p, double* gv, double* state,
+                                                            int nu, int robust) {
+  __shared__ double s_part[kRqSums][kRqSmallThreads / 64];
+  __shared__ double s_sum[kRqSums];
+  __shared__ double s_state[kRqStateWords];
+  const long n = g.nr * g.nc;
+  if (threadIdx.x < kRqStateWords) s_state[threadIdx.x] = state[threadIdx.x];
+  __syncthreads();
+  for (int it = -1; it < nu; ++it) {  // (uniform trip counts: every thread reaches every barrier)
+    const int init = it < 0 ? 1 : (it == 0 ? 2 : 0);
+    // pass 1: p = -g + beta p, then the eight products of {x, p} with {A, M}{x, p}
+    if (init != 1) {
+      const double beta = init == 2 ? 0.0 : s_state[kBeta];
+      for (long k = threadIdx.x; k < n; k += kRqSmallThreads) p[k] = init == 2 ? -gv[k] : -gv[k] + beta * p[k];
+      __syncthreads();
+    }
+    double acc[kRqSums];
+#pragma unroll
+    for (int q = 0; q < kRqSums; ++q) acc[q] = 0.0;
+    for (long k = threadIdx.x; k < n; k += kRqSmallThreads) {
+      const long i = k / g.nc, j = k - i * g.nc;
+      const double xc = x[k], pc = init == 1 ? 0.0 : p[k];
+      const double ax = apply_point(A, 0, x, nullptr, 1.0, 0.0, g.nc, i, j), mx = apply_point(Mo, m_identity, x, nullptr, 1.0, 0.0, g.nc, i, j);
+      const double ap = init == 1 ? 0.0 : apply_point(A, 0, p, nullptr, 1.0, 0.0, g.nc, i, j);
+      const double mp = init == 1 ? 0.0 : apply_point(Mo, m_identity, p, nullptr, 1.0, 0.0, g.nc, i, j);
+      acc[kS_xAx] += xc * ax;
+      acc[kS_xAp] += xc * ap;
+      acc[kS_pAx] += pc * ax;
+      acc[kS_pAp] += pc * ap;
+      acc[kS_xMx] += xc * mx;
+      acc[kS_xMp] += xc * mp;
+      acc[kS_pMx] += pc * mx;
+      acc[kS_pMp] += pc * mp;
+    }
+    small_reduce<kRqSums>(acc, s_part, s_sum);
+    if (threadIdx.x == 0) rq_step_scalars(s_sum, s_state, init, robust);
+    __syncthreads();
+    // pass 2: x += delta p, g = 2 (A x - rho M x), <x, A x>, <x, M x>, <g, g> and (M != I) <g, M g>
+    if (init != 1) {
+      const double delta = s_state[kDelta];
+      for (long k = threadIdx.x; k < n; k += kRqSmallThreads) x[k] = x[k] + delta * p[k];
+      __syncthreads();
+    }
+    const double rho = s_state[kRhoLin];
+    double acc2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long k = threadIdx.x; k < n; k += kRqSmallThreads) {
+      const long i = k / g.nc, j = k - i * g.nc;
+      const double xc = x[k];
+      const double ax = apply_point(A, 0, x, nullptr, 1.0, 0.0, g.nc, i, j), mx = apply_point(Mo, m_identity, x, nullptr, 1.0, 0.0, g.nc, i, j);
+      const double gg = 2.0 * (ax - rho * mx);
+      gv[k] = gg;
+      acc2[0] += xc * ax;
+      acc2[1] += xc * mx;
+      acc2[2] += gg * gg;
+    }
+    if (!m_identity) {
+      __syncthreads();
+      for (long k = threadIdx.x; k < n; k += kRqSmallThreads) {
+        const long i = k / g.nc, j = k - i * g.nc;
+        acc2[3] += gv[k] * apply_point(Mo, 0, gv, nullptr, 1.0, 0.0, g.nc, i, j);
+      }
+    }
+    small_reduce<4>(acc2, s_part, s_sum);
+    if (threadIdx.x == 0) rq_gradient_scalars(s_sum, s_sum[3], s_state, m_identity ? 1 : 0, init);
+    __syncthreads();
+  }
+  if (threadIdx.x < kRqStateWords) state[threadIdx.x] = s_state[threadIdx.x];
 }
 
 // the step after the first real one must use beta = <g1,Mg1>/<g0,Mg0>: scalars2 of the init pair stores <g0,Mg0> and beta
@@ -582,6 +692,15 @@ bool launch_rq_gmg(hipStream_t s, KGrid g, KOp Mo, const double* gv, double* par
 
 void launch_rq_scalars2(hipStream_t s, const double* partials, int nblocks, double* state, int m_identity, int init) {
   hipLaunchKernelGGL(k_rq_scalars2, dim3(1), dim3(256), 0, s, partials, nblocks, state, m_identity, init);
+}
+
+// the whole call in one launch where the level is small enough (k_rq_small): x holds start vector and result, p and gv
+// are work space; false: not taken (the caller runs the passes)
+bool launch_rq_small(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, double* x, double* p, double* gv, double* state, int nu, int robust) {
+  const long n = g.nr * g.nc;
+  if (n > kRqSmallMax || A.nterms < 1 || (!m_identity && Mo.nterms < 1)) return false;
+  hipLaunchKernelGGL(k_rq_small, dim3(1), dim3(kRqSmallThreads), 0, s, g, A, Mo, m_identity, x, p, gv, state, nu, robust);
+  return true;
 }
 
 void launch_rq_store(hipStream_t s, double* state, int word, const double* value) { hipLaunchKernelGGL(k_rq_store, dim3(1), dim3(1), 0, s, state, word, value); }

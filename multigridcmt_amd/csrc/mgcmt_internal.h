@@ -153,6 +153,8 @@ void launch_rq_pass1(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, cons
 int launch_rq_pass2(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const double* x, const double* p, double* xnew, double* gout, double* state,
                     int init, double* partials);
 bool launch_rq_gmg(hipStream_t s, KGrid g, KOp Mo, const double* gv, double* partials, int nblocks);
+// the whole rqmin call (initial pair + nu steps) in one single-workgroup launch where the level is small enough; false: not taken
+bool launch_rq_small(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, double* x, double* p, double* gv, double* state, int nu, int robust);
 // m_identity: 1 = M is the identity, 0 = <g, M g> is in state[rq_word_gmg()], 2 = it is result 3 of the partial sums (launch_rq_gmg)
 void launch_rq_scalars2(hipStream_t s, const double* partials, int nblocks, double* state, int m_identity, int init);
 

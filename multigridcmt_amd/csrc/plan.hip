@@ -1317,6 +1317,10 @@ static int rqmin_impl(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, i
   double* part_dot = p->d_partials + 40000;  // (d_partials holds 67584 doubles: 8 x 4096 for the passes, 1024 for the dot)
   const long n = p->interior(l);
   double* x0 = x;
+  // a level of a few thousand points: the whole call in one launch (MGCMT_RQ_SMALL=0: the passes, for A/B measurements)
+  const char* small_env = getenv("MGCMT_RQ_SMALL");  // (read per call: the tests compare both forms in one process)
+  const bool small_ok = !(small_env && small_env[0] == '0');
+  if (small_ok && launch_rq_small(s, g, A, Mo, m_identity ? 1 : 0, x, pv, gv, st, nu, robust)) return post_launch();
   for (int it = -1; it < nu; ++it) {
     const int init = it < 0 ? 1 : (it == 0 ? 2 : 0);
     launch_rq_pass1(s, g, A, Mo, m_identity ? 1 : 0, x, gv, pv, palt, st, init, robust, part);

@@ -463,3 +463,31 @@ def test_square_well_hamiltonian_against_reference(trio):
     x, rho = solver.rqmin(H, gold["x0"].copy(), sp.eye(g * g), nu=6)
     assert abs(rho - float(gold["rqmin_rho"])) < NORTH_STAR * abs(float(gold["rqmin_rho"]))
     assert rel_err(x, gold["rqmin_x"]) < 1e-8
+
+
+@pytest.mark.parametrize("case", ["1d", "1d_mass", "2d_well", "2d_mass"])
+def test_rqmin_single_launch_equals_the_passes(trio, case, monkeypatch):
+    """Levels of at most 4096 points take the whole rqmin call in one single-workgroup launch (kernels_rq.hip:
+    k_rq_small); MGCMT_RQ_SMALL=0 sends them through the two passes per step the big levels take.  The same arithmetic
+    per point, other summation orders: agreement to rounding (amplified by the steps' conditioning), on the reference's
+    own 1-D problem (RQMin.py:28-33), with a mass operator, and on 2-D levels."""
+    from multigridcmt_amd.operators import potential_well_operator
+    solver, sm, _ = trio
+    if case.startswith("1d"):
+        n = 64
+        A = (-1 / np.pi ** 2) * sm.laplacian(n)
+        M = sp.eye(n) if case == "1d" else sp.diags([np.full(n - 1, 1 / 6), np.full(n, 2 / 3), np.full(n - 1, 1 / 6)], [-1, 0, 1])
+        x0 = np.random.RandomState(3).rand(n)
+    else:
+        g = 32
+        A = potential_well_operator(g, depth=30.0, inner=(8, 24)).tocsr() if case == "2d_well" else (-1 / np.pi ** 2) * sm.laplacian(g, dimension="2d")
+        m1 = sp.diags([np.full(g - 1, 1 / 6), np.full(g, 2 / 3), np.full(g - 1, 1 / 6)], [-1, 0, 1])
+        M = sp.eye(g * g) if case == "2d_well" else sp.kron(m1, m1)
+        x0 = np.random.RandomState(3).rand(g * g)
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("MGCMT_RQ_SMALL", form)
+        out[form] = solver.rqmin(A.tocsr(), x0.copy(), sp.csr_matrix(M), nu=5)
+    (x1, rho1), (x0_, rho0) = out["1"], out["0"]
+    assert abs(rho1 - rho0) < 1e-12 * abs(rho0)
+    assert rel_err(x1, x0_) < 1e-10
