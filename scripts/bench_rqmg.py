@@ -1,6 +1,6 @@
 """Device time of one cycle of the reference's Rayleigh-quotient multigrid (MGCMTSolver.vcycle_rqmg, MGCMTSolver.py:99-122,
 with the 2-D transfers) on the 2-D square well of BASELINE config 5, the iterate resident on the GPU: rqmin as two passes
-per step (csrc/kernels_rq.hip).  usage: bench_rqmg.py [grid] [nu]"""
+per step (csrc/kernels_rq.hip).  usage: bench_rqmg.py [grid] [nu] [cycles-only]"""
 import json
 import os
 import sys
@@ -31,6 +31,9 @@ for _ in range(n):
     rhos.append(S._rqmg_levels(plan, 0, nu, nu)[1])
 plan.sync()
 ms = (time.perf_counter() - t0) / n * 1e3
+if len(sys.argv) > 3:  # (for kernel traces: nothing but cycles)
+    print(json.dumps({"ms_per_cycle": ms, "cycles_run": 2 + n}))
+    sys.exit(0)
 # one rqmin call alone on the finest level: nu steps of 64 B per point + the initial pair (x read twice, g written: 24 B)
 plan.sync()
 t0 = time.perf_counter()

@@ -111,6 +111,7 @@ inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, 
   hipmock::run_grid(grid, block, [=]() { kernel(args...); });
 }
 
+inline void __threadfence() {}
 inline unsigned atomicAdd(unsigned* p, unsigned x) { const unsigned old = *p; *p = old + x; return old; }  // one fiber runs at a time
 
 hipError_t hipMalloc(void** p, size_t bytes);
