@@ -121,7 +121,31 @@ __device__ __forceinline__ void apply2(const KOp& op, const Fac<M>& f, long i, c
 constexpr int kRqThreads = 256;
 constexpr int kRqSums = 8;
 
-// per block: nq partial sums into partials[q * nblocks + block] (fixed order: deterministic)
+// A block's partial sums are read by ANOTHER workgroup of the same launch (rq_tail below), on another CU and possibly
+// another XCD, whose L2 is not coherent with this one's.  Fences would do (release here, acquire there) but an agent-scope
+// release writes back the XCD's L2 and the acquire invalidates the CU's L1, per BLOCK: measured, a __threadfence() pair
+// in the tail made the fine-level passes 3.1x slower (2.15 -> 6.65 ms per call at 8192^2).  The hand-off used instead is
+// MI355X_MICROARCH.md's fence-free one: the sums are stored write-through (`sc1`), the storing wave waits for the
+// stores' acknowledgement, then one of its lanes adds to the ticket counter; the workgroup whose add came last reads
+// them with `sc1` loads (past its L1, from memory).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void store_partial(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_partial(const double* p) {
+  return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void clear_ticket(unsigned* p) { __hip_atomic_store(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+__device__ __forceinline__ void store_partial(double* p, double v) { *p = v; }
+__device__ __forceinline__ double load_partial(const double* p) { return *p; }
+__device__ __forceinline__ void stores_acknowledged() {}
+__device__ __forceinline__ void clear_ticket(unsigned* p) { *p = 0u; }
+#endif
+
+// per block: nq partial sums into partials[q * nblocks + block] (fixed order: deterministic); the storing lanes belong to
+// wave 0, which has seen the stores acknowledged when this returns
 template <int NQ>
 __device__ __forceinline__ void block_partials(const double* acc, double (*s_part)[kRqThreads / 64], double* partials, int nblocks, int block) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -137,8 +161,9 @@ __device__ __forceinline__ void block_partials(const double* acc, double (*s_par
     double t = 0.0;
     const int nw = blockDim.x >> 6;
     for (int k = 0; k < nw; ++k) t += s_part[threadIdx.x][k];
-    partials[(long)threadIdx.x * nblocks + block] = t;
+    store_partial(partials + (long)threadIdx.x * nblocks + block, t);
   }
+  if (threadIdx.x < 64) stores_acknowledged();
 }
 
 // ---- the scalars of a pass, computed by the pass itself ---------------------------------------------------------------
@@ -147,7 +172,8 @@ __device__ __forceinline__ void block_partials(const double* acc, double (*s_par
 // big level's pass (measured: 126 such launches, 0.96 ms of an 8.2 ms cycle at 8192^2).  Instead the LAST workgroup of
 // the pass to finish does it: every block publishes its partial sums, then takes a ticket; the one that draws the last
 // ticket adds all blocks' sums up (in block order, so the result does not depend on which block that was) and writes
-// the state words the next pass reads.
+// the state words the next pass reads.  (k_rq_gmg adds result 3 to the partial sums of the pass-2 launch before it: those
+// were written through and the launch has ended.)
 struct RqTail {
   unsigned* ticket;  // zero between launches
   int kind;          // 0: none (a kernel follows that does it), 1: the step's scalars (pass 1), 2: rho and beta (pass 2, <g, M g>)
@@ -163,17 +189,15 @@ __device__ __forceinline__ void rq_tail(const RqTail& t, const double* partials,
   if (t.kind == 0) return;  // (uniform)
   __shared__ int s_last;
   __shared__ double s_res[kRqSums];
-  __threadfence();  // this block's partial sums: visible to the device before its ticket is
-  __syncthreads();
+  // (block_partials: wave 0 stored this block's sums and has seen them acknowledged)
   if (threadIdx.x == 0) s_last = atomicAdd(t.ticket, 1u) + 1u == (unsigned)nblocks ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   reduce_results(partials, nblocks, t.kind == 1 ? kRqSums : (t.mflag == 2 ? 4 : 3), s_res);
   if (threadIdx.x != 0) return;
   if (t.kind == 1) rq_step_scalars(s_res, state, init, t.robust);
   else rq_gradient_scalars(s_res, t.mflag == 2 ? s_res[3] : state[kGMG], state, t.mflag, init);
-  *t.ticket = 0u;
+  clear_ticket(t.ticket);
 }
 
 // ---- row march (2-D, even sizes) ------------------------------------------------------------------------------
@@ -408,15 +432,6 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2_point(KGrid g, KOp A, K
 }
 
 // ---- scalars --------------------------------------------------------------------------------------------------
-
-// a number another workgroup of the same launch has written (its partial sums): read past this CU's caches
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ double load_partial(const double* p) {
-  return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-#else
-__device__ __forceinline__ double load_partial(const double* p) { return *p; }
-#endif
 
 // results' per-block partial sums -> s_out[q]: one wave per result (lane-strided, then a fixed shuffle tree), the waves
 // of the block taking the results in turn — the same order of additions whatever the block size
