@@ -30,7 +30,6 @@ namespace {
 enum {
   kS_xAx = 0, kS_xAp, kS_pAx, kS_pAp, kS_xMx, kS_xMp, kS_pMx, kS_pMp,  // pass 1
   kDelta = 8, kRho, kBeta, kGMGprev, kGMG, kStop, kXAXn, kXMXn, kGG, kRhoLin,
-  kTicket = 31,  // (an unsigned, not a double: the passes' ticket counter, zero between launches)
   kRqStateWords = 32
 };
 
@@ -121,33 +120,9 @@ __device__ __forceinline__ void apply2(const KOp& op, const Fac<M>& f, long i, c
 constexpr int kRqThreads = 256;
 constexpr int kRqSums = 8;
 
-// A block's partial sums are read by ANOTHER workgroup of the same launch (rq_tail below), on another CU and possibly
-// another XCD, whose L2 is not coherent with this one's.  Fences would do (release here, acquire there) but an agent-scope
-// release writes back the XCD's L2 and the acquire invalidates the CU's L1, per BLOCK: measured, a __threadfence() pair
-// in the tail made the fine-level passes 3.1x slower (2.15 -> 6.65 ms per call at 8192^2).  The hand-off used instead is
-// MI355X_MICROARCH.md's fence-free one: the sums are stored write-through (`sc1`), the storing wave waits for the
-// stores' acknowledgement, then one of its lanes adds to the ticket counter; the workgroup whose add came last reads
-// them with `sc1` loads (past its L1, from memory).
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ void store_partial(double* p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double load_partial(const double* p) {
-  return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void clear_ticket(unsigned* p) { __hip_atomic_store(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#else
-__device__ __forceinline__ void store_partial(double* p, double v) { *p = v; }
-__device__ __forceinline__ double load_partial(const double* p) { return *p; }
-__device__ __forceinline__ void stores_acknowledged() {}
-__device__ __forceinline__ void clear_ticket(unsigned* p) { *p = 0u; }
-#endif
-
-// per block: nq partial sums into partials[q * nblocks + block] (fixed order: deterministic); the storing lanes belong to
-// wave 0, which has seen the stores acknowledged when this returns
+// per block: nq partial sums into partials[q * nblocks + block] (fixed order: deterministic)
 template <int NQ>
-__device__ __forceinline__ void block_partials(const double* acc, double (*s_part)[kRqThreads / 64], double* partials, int nblocks, int block) {
+__device__ __forceinline__ void block_partials(const double* acc, double (*s_part)[kRqThreads / 64], double* __restrict__ partials, int nblocks, int block) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -161,43 +136,8 @@ __device__ __forceinline__ void block_partials(const double* acc, double (*s_par
     double t = 0.0;
     const int nw = blockDim.x >> 6;
     for (int k = 0; k < nw; ++k) t += s_part[threadIdx.x][k];
-    store_partial(partials + (long)threadIdx.x * nblocks + block, t);
+    partials[(long)threadIdx.x * nblocks + block] = t;
   }
-  if (threadIdx.x < 64) stores_acknowledged();
-}
-
-// ---- the scalars of a pass, computed by the pass itself ---------------------------------------------------------------
-// Every pass is followed by a handful of scalar operations on its sums (the 2 x 2 pencil; rho and beta).  As a one-block
-// kernel of its own that costs a launch per pass — 4 - 8 us of an otherwise idle GPU on the small levels, 20 + us behind a
-// big level's pass (measured: 126 such launches, 0.96 ms of an 8.2 ms cycle at 8192^2).  Instead the LAST workgroup of
-// the pass to finish does it: every block publishes its partial sums, then takes a ticket; the one that draws the last
-// ticket adds all blocks' sums up (in block order, so the result does not depend on which block that was) and writes
-// the state words the next pass reads.  (k_rq_gmg adds result 3 to the partial sums of the pass-2 launch before it: those
-// were written through and the launch has ended.)
-struct RqTail {
-  unsigned* ticket;  // zero between launches
-  int kind;          // 0: none (a kernel follows that does it), 1: the step's scalars (pass 1), 2: rho and beta (pass 2, <g, M g>)
-  int robust;        // kind 1
-  int mflag;         // kind 2: 1 = M is the identity, 0 = <g, M g> is in the state, 2 = it is result 3 of the partial sums
-};
-
-__device__ __forceinline__ void reduce_results(const double* __restrict__ partials, int nblocks, int nq, double* s_out);
-__device__ void rq_step_scalars(const double* s, double* __restrict__ state, int init, int robust);
-__device__ void rq_gradient_scalars(const double* s, double gmg_in, double* __restrict__ state, int m_identity, int init);
-
-__device__ __forceinline__ void rq_tail(const RqTail& t, const double* partials, int nblocks, double* state, int init) {
-  if (t.kind == 0) return;  // (uniform)
-  __shared__ int s_last;
-  __shared__ double s_res[kRqSums];
-  // (block_partials: wave 0 stored this block's sums and has seen them acknowledged)
-  if (threadIdx.x == 0) s_last = atomicAdd(t.ticket, 1u) + 1u == (unsigned)nblocks ? 1 : 0;
-  __syncthreads();
-  if (!s_last) return;
-  reduce_results(partials, nblocks, t.kind == 1 ? kRqSums : (t.mflag == 2 ? 4 : 3), s_res);
-  if (threadIdx.x != 0) return;
-  if (t.kind == 1) rq_step_scalars(s_res, state, init, t.robust);
-  else rq_gradient_scalars(s_res, t.mflag == 2 ? s_res[3] : state[kGMG], state, t.mflag, init);
-  clear_ticket(t.ticket);
 }
 
 // ---- row march (2-D, even sizes) ------------------------------------------------------------------------------
@@ -229,8 +169,8 @@ __device__ __forceinline__ Row4 load4(const double* __restrict__ u, const double
 
 template <int MA, int MM>
 __global__ void __launch_bounds__(kRqThreads) k_rq_pass1(KGrid g, KOp A, KOp Mo, const double* __restrict__ x, const double* __restrict__ gv,
-                                                        const double* __restrict__ pold, double* __restrict__ pnew, double* state, int init, int rows,
-                                                        double* partials, int nblocks, RqTail tail) {
+                                                        const double* __restrict__ pold, double* __restrict__ pnew, const double* __restrict__ state,
+                                                        int init, int rows, double* __restrict__ partials, int nblocks) {
   __shared__ double s_part[kRqSums][kRqThreads / 64];
   const long j = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
   const long nc = g.nc;
@@ -277,13 +217,12 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass1(KGrid g, KOp A, KOp Mo,
     }
   }
   block_partials<kRqSums>(acc, s_part, partials, nblocks, (int)(blockIdx.y * gridDim.x + blockIdx.x));
-  rq_tail(tail, partials, nblocks, state, init);
 }
 
 template <int MA, int MM>
 __global__ void __launch_bounds__(kRqThreads) k_rq_pass2(KGrid g, KOp A, KOp Mo, const double* __restrict__ x, const double* __restrict__ p,
-                                                        double* __restrict__ xnew, double* __restrict__ gout, double* state, int init, int rows,
-                                                        double* partials, int nblocks, RqTail tail) {
+                                                        double* __restrict__ xnew, double* __restrict__ gout, const double* __restrict__ state, int init,
+                                                        int rows, double* __restrict__ partials, int nblocks) {
   __shared__ double s_part[3][kRqThreads / 64];
   const long j = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
   const long nc = g.nc;
@@ -317,13 +256,11 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2(KGrid g, KOp A, KOp Mo,
     }
   }
   block_partials<3>(acc, s_part, partials, nblocks, (int)(blockIdx.y * gridDim.x + blockIdx.x));
-  rq_tail(tail, partials, nblocks, state, init);
 }
 
 // <g, M g> for M != I without storing M g: the march over g alone, result 3 of the pass-2 partial sums (same grid)
 template <int MM>
-__global__ void __launch_bounds__(kRqThreads) k_rq_gmg(KGrid g, KOp Mo, const double* __restrict__ gv, int rows, double* partials, int nblocks, double* state, int init,
-                                                      RqTail tail) {
+__global__ void __launch_bounds__(kRqThreads) k_rq_gmg(KGrid g, KOp Mo, const double* __restrict__ gv, int rows, double* __restrict__ partials, int nblocks) {
   __shared__ double s_part[1][kRqThreads / 64];
   const long j = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
   const long nc = g.nc;
@@ -347,7 +284,6 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_gmg(KGrid g, KOp Mo, const do
     }
   }
   block_partials<1>(acc, s_part, partials + 3L * nblocks, nblocks, (int)(blockIdx.y * gridDim.x + blockIdx.x));
-  rq_tail(tail, partials, nblocks, state, init);
 }
 
 // ---- one thread per point (1-D levels, odd shapes): the same arithmetic through direct neighbour loads ---------------
@@ -380,7 +316,7 @@ __device__ __forceinline__ double apply_point(const KOp& op, int identity, const
 
 __global__ void __launch_bounds__(kRqThreads) k_rq_pass1_point(KGrid g, KOp A, KOp Mo, int m_identity, const double* __restrict__ x,
                                                               const double* __restrict__ gv, const double* __restrict__ pold, double* __restrict__ pnew,
-                                                              double* state, int init, double* partials, int nblocks, RqTail tail) {
+                                                              const double* __restrict__ state, int init, double* __restrict__ partials, int nblocks) {
   __shared__ double s_part[kRqSums][kRqThreads / 64];
   const long n = g.nr * g.nc;
   const double beta = init ? 0.0 : state[kBeta];
@@ -405,12 +341,11 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass1_point(KGrid g, KOp A, K
     if (init != 1) pnew[k] = pc;
   }
   block_partials<kRqSums>(acc, s_part, partials, nblocks, (int)blockIdx.x);
-  rq_tail(tail, partials, nblocks, state, init);
 }
 
 __global__ void __launch_bounds__(kRqThreads) k_rq_pass2_point(KGrid g, KOp A, KOp Mo, int m_identity, const double* __restrict__ x,
                                                               const double* __restrict__ p, double* __restrict__ xnew, double* __restrict__ gout,
-                                                              double* state, int init, double* partials, int nblocks, RqTail tail) {
+                                                              const double* __restrict__ state, int init, double* __restrict__ partials, int nblocks) {
   __shared__ double s_part[3][kRqThreads / 64];
   const long n = g.nr * g.nc;
   const double delta = state[kDelta], rho = state[kRhoLin];
@@ -428,30 +363,21 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2_point(KGrid g, KOp A, K
     acc[2] += gg * gg;
   }
   block_partials<3>(acc, s_part, partials, nblocks, (int)blockIdx.x);
-  rq_tail(tail, partials, nblocks, state, init);
 }
 
 // ---- scalars --------------------------------------------------------------------------------------------------
 
-// results' per-block partial sums -> s_out[q]: one wave per result (lane-strided, then a fixed shuffle tree), the waves
-// of the block taking the results in turn — the same order of additions whatever the block size
+// results' per-block partial sums -> s_out[q]: one wave per result (lane-strided, then a fixed shuffle tree); the block
+// has at least nq waves
 __device__ __forceinline__ void reduce_results(const double* __restrict__ partials, int nblocks, int nq, double* s_out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  for (int q = wave; q < nq; q += nwaves) {
-    const double* src = partials + (long)q * nblocks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < nq) {
+    const double* src = partials + (long)wave * nblocks;
     double acc = 0.0;
-    int i = lane;
-    for (; i + 192 < nblocks; i += 256) {  // (four loads in flight; added in index order)
-      const double t0 = load_partial(src + i), t1 = load_partial(src + i + 64), t2 = load_partial(src + i + 128), t3 = load_partial(src + i + 192);
-      acc += t0;
-      acc += t1;
-      acc += t2;
-      acc += t3;
-    }
-    for (; i < nblocks; i += 64) acc += load_partial(src + i);
+    for (int i = lane; i < nblocks; i += 64) acc += src[i];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
-    if (lane == 0) s_out[q] = acc;
+    if (lane == 0) s_out[wave] = acc;
   }
   __syncthreads();
 }
@@ -550,8 +476,15 @@ __global__ void __launch_bounds__(256) k_rq_scalars2(const double* __restrict__ 
 // initial pair + nu steps start to end: vectors updated in place in global memory (they stay in the CU's L1 / L2), the
 // sums reduced in LDS, the scalars of both passes computed by thread 0 into an LDS copy of the state block — the same
 // arithmetic as the pass kernels, block barriers where those have kernel boundaries.  Measured per step (MI355X, 3-term
-// operator, M != I): ~10 us up to 32^2, where the passes take ~25; with four points per thread (64^2) 60 us — slower
-// than the passes, hence one point per thread.
+// operator, M != I): ~10 us up to 32^2, where the passes and their scalar kernels take ~25; with four points per thread
+// (64^2) 60 us — slower than the passes, hence one point per thread.
+//
+// (Tried and dropped: the scalars of a pass computed by the LAST workgroup of the pass itself — partial sums stored
+// write-through, a ticket counter, `sc1` loads — instead of one-block kernels behind it: 126 launches fewer per 8192^2
+// cycle, but the cycle went from 7.7 - 7.9 to 8.2 - 8.4 ms on the same box.  Thousands of workgroups finishing together
+// serialise on the one ticket word (k_rq_gmg at 2048 blocks: 23 -> 40 us) and on the small levels ticket + `sc1` loads
+// cost what the launch did (6.4 -> 12.6 us).  With __threadfence() in place of the write-through hand-off the
+// fine-level passes ran 3.1x slower: an agent-scope release per block writes back the XCD's L2.)
 constexpr int kRqSmallThreads = 1024;
 constexpr int kRqSmallMax = kRqSmallThreads;
 
@@ -580,7 +513,7 @@ __global__ void __launch_bounds__(kRqSmallThreads) k_rq_small(KGrid g, KOp A, KO
   __shared__ double s_sum[kRqSums];
   __shared__ double s_state[kRqStateWords];
   const long n = g.nr * g.nc;
-  if (threadIdx.x < kTicket) s_state[threadIdx.x] = state[threadIdx.x];
+  if (threadIdx.x < kRqStateWords) s_state[threadIdx.x] = state[threadIdx.x];
   __syncthreads();
   for (int it = -1; it < nu; ++it) {  // (uniform trip counts: every thread reaches every barrier)
     const int init = it < 0 ? 1 : (it == 0 ? 2 : 0);
@@ -640,7 +573,7 @@ __global__ void __launch_bounds__(kRqSmallThreads) k_rq_small(KGrid g, KOp A, KO
     if (threadIdx.x == 0) rq_gradient_scalars(s_sum, s_sum[3], s_state, m_identity ? 1 : 0, init);
     __syncthreads();
   }
-  if (threadIdx.x < kTicket) state[threadIdx.x] = s_state[threadIdx.x];
+  if (threadIdx.x < kRqStateWords) state[threadIdx.x] = s_state[threadIdx.x];
 }
 
 // the step after the first real one must use beta = <g1,Mg1>/<g0,Mg0>: scalars2 of the init pair stores <g0,Mg0> and beta
@@ -649,21 +582,19 @@ __global__ void k_rq_store(double* __restrict__ state, int word, const double* _
 
 template <int MA>
 void launch_pass1_ma(hipStream_t s, int mm, dim3 grid, dim3 block, KGrid g, const KOp& A, const KOp& Mo, const double* x, const double* gv,
-                     const double* pold, double* pnew, double* state, int init, int rows, double* partials, int nblocks, RqTail tail) {
-  if (mm == 0) hipLaunchKernelGGL((k_rq_pass1<MA, 0>), grid, block, 0, s, g, A, Mo, x, gv, pold, pnew, state, init, rows, partials, nblocks, tail);
-  else hipLaunchKernelGGL((k_rq_pass1<MA, 1>), grid, block, 0, s, g, A, Mo, x, gv, pold, pnew, state, init, rows, partials, nblocks, tail);
+                     const double* pold, double* pnew, const double* state, int init, int rows, double* partials, int nblocks) {
+  if (mm == 0) hipLaunchKernelGGL((k_rq_pass1<MA, 0>), grid, block, 0, s, g, A, Mo, x, gv, pold, pnew, state, init, rows, partials, nblocks);
+  else hipLaunchKernelGGL((k_rq_pass1<MA, 1>), grid, block, 0, s, g, A, Mo, x, gv, pold, pnew, state, init, rows, partials, nblocks);
 }
 
 template <int MA>
 void launch_pass2_ma(hipStream_t s, int mm, dim3 grid, dim3 block, KGrid g, const KOp& A, const KOp& Mo, const double* x, const double* p,
-                     double* xnew, double* gout, double* state, int init, int rows, double* partials, int nblocks, RqTail tail) {
-  if (mm == 0) hipLaunchKernelGGL((k_rq_pass2<MA, 0>), grid, block, 0, s, g, A, Mo, x, p, xnew, gout, state, init, rows, partials, nblocks, tail);
-  else hipLaunchKernelGGL((k_rq_pass2<MA, 1>), grid, block, 0, s, g, A, Mo, x, p, xnew, gout, state, init, rows, partials, nblocks, tail);
+                     double* xnew, double* gout, const double* state, int init, int rows, double* partials, int nblocks) {
+  if (mm == 0) hipLaunchKernelGGL((k_rq_pass2<MA, 0>), grid, block, 0, s, g, A, Mo, x, p, xnew, gout, state, init, rows, partials, nblocks);
+  else hipLaunchKernelGGL((k_rq_pass2<MA, 1>), grid, block, 0, s, g, A, Mo, x, p, xnew, gout, state, init, rows, partials, nblocks);
 }
 
 // which instantiation serves A (see Fac): the 5-point forms where the plan recognised one, the general terms otherwise
-unsigned* ticket_of(double* state) { return reinterpret_cast<unsigned*>(state + kTicket); }
-
 int operator_form(const KOp& A) {
   if (A.five_point && A.cn != 0.0) return kFive;
   if (A.five_diag && A.ndiag >= 1 && A.ndiag <= 2) return kFive + A.ndiag;
@@ -687,7 +618,6 @@ int rq_word_gmg() { return kGMG; }
 void launch_rq_pass1(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const double* x, const double* gv, const double* pold, double* pnew,
                      double* state, int init, int robust, double* partials) {
   int nblocks;
-  const RqTail tail{ticket_of(state), 1, robust, 0};  // the pass's last block computes the step's scalars
   if (march_ok(g, A, Mo, m_identity, x, gv, pold, pnew, x)) {
     const dim3 b(g.nc >= 512 ? kRqThreads : 64, 1, 1);
     const unsigned gx = (unsigned)((g.nc / 2 + b.x - 1) / b.x);
@@ -701,29 +631,28 @@ void launch_rq_pass1(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, cons
     nblocks = (int)(grid.x * grid.y);
     const int mm = m_identity ? 0 : 1;
     switch (operator_form(A)) {
-      case 1: launch_pass1_ma<1>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks, tail); break;
-      case 2: launch_pass1_ma<2>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks, tail); break;
-      case 3: launch_pass1_ma<3>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks, tail); break;
-      case 4: launch_pass1_ma<4>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks, tail); break;
-      case kFive: launch_pass1_ma<kFive>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks, tail); break;
-      case kFive + 1: launch_pass1_ma<kFive + 1>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks, tail); break;
-      default: launch_pass1_ma<kFive + 2>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks, tail); break;
+      case 1: launch_pass1_ma<1>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      case 2: launch_pass1_ma<2>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      case 3: launch_pass1_ma<3>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      case 4: launch_pass1_ma<4>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      case kFive: launch_pass1_ma<kFive>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      case kFive + 1: launch_pass1_ma<kFive + 1>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
+      default: launch_pass1_ma<kFive + 2>(s, mm, grid, b, g, A, Mo, x, gv, pold, pnew, state, init, (int)rows, partials, nblocks); break;
     }
   } else {
     const long n = g.nr * g.nc;
     long blocks = (n + kRqThreads - 1) / kRqThreads;
     if (blocks > 1024) blocks = 1024;
     nblocks = (int)blocks;
-    hipLaunchKernelGGL(k_rq_pass1_point, dim3((unsigned)blocks), dim3(kRqThreads), 0, s, g, A, Mo, m_identity, x, gv, pold, pnew, state, init, partials, nblocks, tail);
+    hipLaunchKernelGGL(k_rq_pass1_point, dim3((unsigned)blocks), dim3(kRqThreads), 0, s, g, A, Mo, m_identity, x, gv, pold, pnew, state, init, partials, nblocks);
   }
+  hipLaunchKernelGGL(k_rq_scalars1, dim3(1), dim3(64 * kRqSums), 0, s, partials, nblocks, state, init, robust);
 }
 
-// pass 2; with M = I its last block computes rho and beta, otherwise <g, M g> is still missing: launch_rq_gmg, or the
-// caller puts it into the state and calls launch_rq_scalars2
+// pass 2 without its scalars (the caller may have to put <g, M g> into the state first)
 int launch_rq_pass2(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const double* x, const double* p, double* xnew, double* gout, double* state,
                     int init, double* partials) {
   int nblocks;
-  const RqTail tail{ticket_of(state), m_identity ? 2 : 0, 0, 1};
   if (march_ok(g, A, Mo, m_identity, x, p, xnew, gout, x)) {
     const dim3 b(g.nc >= 512 ? kRqThreads : 64, 1, 1);
     const unsigned gx = (unsigned)((g.nc / 2 + b.x - 1) / b.x);
@@ -737,28 +666,27 @@ int launch_rq_pass2(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const
     nblocks = (int)(grid.x * grid.y);
     const int mm = m_identity ? 0 : 1;
     switch (operator_form(A)) {
-      case 1: launch_pass2_ma<1>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks, tail); break;
-      case 2: launch_pass2_ma<2>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks, tail); break;
-      case 3: launch_pass2_ma<3>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks, tail); break;
-      case 4: launch_pass2_ma<4>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks, tail); break;
-      case kFive: launch_pass2_ma<kFive>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks, tail); break;
-      case kFive + 1: launch_pass2_ma<kFive + 1>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks, tail); break;
-      default: launch_pass2_ma<kFive + 2>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks, tail); break;
+      case 1: launch_pass2_ma<1>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      case 2: launch_pass2_ma<2>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      case 3: launch_pass2_ma<3>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      case 4: launch_pass2_ma<4>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      case kFive: launch_pass2_ma<kFive>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      case kFive + 1: launch_pass2_ma<kFive + 1>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
+      default: launch_pass2_ma<kFive + 2>(s, mm, grid, b, g, A, Mo, x, p, xnew, gout, state, init, (int)rows, partials, nblocks); break;
     }
   } else {
     const long n = g.nr * g.nc;
     long blocks = (n + kRqThreads - 1) / kRqThreads;
     if (blocks > 1024) blocks = 1024;
     nblocks = (int)blocks;
-    hipLaunchKernelGGL(k_rq_pass2_point, dim3((unsigned)blocks), dim3(kRqThreads), 0, s, g, A, Mo, m_identity, x, p, xnew, gout, state, init, partials, nblocks, tail);
+    hipLaunchKernelGGL(k_rq_pass2_point, dim3((unsigned)blocks), dim3(kRqThreads), 0, s, g, A, Mo, m_identity, x, p, xnew, gout, state, init, partials, nblocks);
   }
   return nblocks;
 }
 
-// <g, M g> as result 3 of pass 2's partial sums (march levels with a one-term M), then rho and beta by the kernel's last
-// block: true when launched; false: the caller computes <g, M g> (application + dot product) into state[rq_word_gmg()]
-// and calls launch_rq_scalars2
-bool launch_rq_gmg(hipStream_t s, KGrid g, KOp Mo, const double* gv, double* partials, int nblocks, double* state, int init) {
+// <g, M g> into result 3 of pass 2's partial sums (march levels with a one-term M): true when launched — launch_rq_scalars2
+// then takes m_identity = 2; false: the caller computes it (application + dot product) into state[rq_word_gmg()]
+bool launch_rq_gmg(hipStream_t s, KGrid g, KOp Mo, const double* gv, double* partials, int nblocks) {
   if (!(g.coarsen_rows && g.nr >= 2 && g.nc >= 2 && (g.nc & 1) == 0 && (((uintptr_t)gv) & 15) == 0 && Mo.nterms == 1)) return false;
   const dim3 b(g.nc >= 512 ? kRqThreads : 64, 1, 1);
   const unsigned gx = (unsigned)((g.nc / 2 + b.x - 1) / b.x);
@@ -767,7 +695,7 @@ bool launch_rq_gmg(hipStream_t s, KGrid g, KOp Mo, const double* gv, double* par
   while (rows > 2 && (long)gx * ((g.nr + rows - 1) / rows) < 2048) rows /= 2;
   const dim3 grid(gx, (unsigned)((g.nr + rows - 1) / rows), 1);
   if ((int)(grid.x * grid.y) != nblocks) return false;  // (pass 2 took the point form: another block count)
-  hipLaunchKernelGGL((k_rq_gmg<1>), grid, b, 0, s, g, Mo, gv, (int)rows, partials, nblocks, state, init, RqTail{ticket_of(state), 2, 0, 2});
+  hipLaunchKernelGGL((k_rq_gmg<1>), grid, b, 0, s, g, Mo, gv, (int)rows, partials, nblocks);
   return true;
 }
 

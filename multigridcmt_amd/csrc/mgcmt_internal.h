@@ -141,11 +141,10 @@ void launch_lincomb(hipStream_t s, long n, const double* const* v, const double*
 bool mgs_small_fits(long n);
 
 // Rayleigh-quotient minimisation as two passes per step (kernels_rq.hip); state: rq_state_words() doubles on the device,
-// zeroed once; partials: at least 8 * 4096 doubles.  init: 1 = the initial pair (p = 0: rho and g of the start vector),
-// 2 = the first step (p = -g, p_old not read), 0 = a step.  The scalars between the passes (delta and rho of x + delta p
-// after pass 1; rho and beta after pass 2) are computed by the last workgroup of the pass itself, except where <g, M g>
-// needs a kernel of its own: launch_rq_gmg does both, or the caller computes it and calls launch_rq_scalars2 with the
-// number of partial sums per result that launch_rq_pass2 returned.
+// partials: at least 8 * 4096 doubles.  init: 1 = the initial pair (p = 0: rho and g of the start vector), 2 = the first
+// step (p = -g, p_old not read), 0 = a step.  launch_rq_pass1 ends with the step's scalars (delta, rho of x + delta p);
+// launch_rq_pass2 returns the number of partial sums per result for launch_rq_scalars2 (rho, beta), which the caller
+// runs after <g, M g> is in state[rq_word_gmg()] when M is not the identity.
 int rq_state_words();
 int rq_word_rho();
 int rq_word_gmg();
@@ -153,7 +152,7 @@ void launch_rq_pass1(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, cons
                      double* state, int init, int robust, double* partials);
 int launch_rq_pass2(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const double* x, const double* p, double* xnew, double* gout, double* state,
                     int init, double* partials);
-bool launch_rq_gmg(hipStream_t s, KGrid g, KOp Mo, const double* gv, double* partials, int nblocks, double* state, int init);
+bool launch_rq_gmg(hipStream_t s, KGrid g, KOp Mo, const double* gv, double* partials, int nblocks);
 // the whole rqmin call (initial pair + nu steps) in one single-workgroup launch where the level is small enough; false: not taken
 bool launch_rq_small(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, double* x, double* p, double* gv, double* state, int nu, int robust);
 // m_identity: 1 = M is the identity, 0 = <g, M g> is in state[rq_word_gmg()], 2 = it is result 3 of the partial sums (launch_rq_gmg)

@@ -1327,13 +1327,17 @@ static int rqmin_impl(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, i
     if (init != 1) std::swap(pv, palt);
     const int nb = launch_rq_pass2(s, g, A, Mo, m_identity ? 1 : 0, x, pv, xalt, gv, st, init, part);
     if (init != 1) std::swap(x, xalt);  // (the initial pair leaves x where it is)
-    // M = I: pass 2 has computed rho and beta itself.  Otherwise <g, M g> first: one more march over g (nothing stored)
-    // where the level takes the march, which then ends with them; application + dot product + a scalar kernel elsewhere
-    if (!m_identity && !launch_rq_gmg(s, g, Mo, gv, part, nb, st, init)) {
-      launch_apply(s, g, Mo, KVec{gv, 0}, KVec{tmp, 0}, p->d_zero, 1);
-      launch_dots(s, n, gv, tmp, 0, 1, part_dot, st + rq_word_gmg());
-      launch_rq_scalars2(s, part, nb, st, 0, init);
+    int mflag = m_identity ? 1 : 0;
+    if (!m_identity) {
+      // <g, M g>: one more march over g (nothing stored) where the level takes the march; application + dot product elsewhere
+      if (launch_rq_gmg(s, g, Mo, gv, part, nb)) {
+        mflag = 2;
+      } else {
+        launch_apply(s, g, Mo, KVec{gv, 0}, KVec{tmp, 0}, p->d_zero, 1);
+        launch_dots(s, n, gv, tmp, 0, 1, part_dot, st + rq_word_gmg());
+      }
     }
+    launch_rq_scalars2(s, part, nb, st, mflag, init);
   }
   MG_TRY(post_launch());
   if (x != x0) MG_HIP(hipMemcpyAsync(x0, x, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
