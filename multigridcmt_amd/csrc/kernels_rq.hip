@@ -70,9 +70,38 @@ __device__ __forceinline__ void load_fac(const KOp& op, long j, Fac<M>& f) {
   }
 }
 
-// (Op v) at (i, j) and (i, j+1) from the rows above / at / below; M == 0: the identity.  eval_point's terms.
+// A Kronecker term applied along a march: (X (x) Y) v at row i is xl (Y v_{i-1}) + xd (Y v_i) + xu (Y v_{i+1}) — the row
+// transforms Y v_r (three multiply-adds per point and term) are computed ONCE, when row r is loaded, and carried down
+// the march with the rows themselves; combining three of them takes three more.  Six multiply-adds per point and term
+// where evaluating the 9-point stencil of every term at every point takes twelve: on the Galerkin levels — every term
+// a full 9-point stencil, M too — these passes are bound by the vector ALUs, not by memory (pass 1 at 4096^2 with three
+// terms in A and one in M: 140 us for 0.54 GB).
 template <int M>
-__device__ __forceinline__ void apply2(const KOp& op, const Fac<M>& f, long i, const Row4& n, const Row4& c, const Row4& s, double& ra, double& rb) {
+struct RowT {
+  static constexpr int T = (M >= 1 && M <= 4) ? M : 1;
+  double a[T], b[T];  // per term: (Y v)(r, j), (Y v)(r, j + 1)
+};
+
+template <int M>
+__device__ __forceinline__ RowT<M> transform(const Fac<M>& f, const Row4& r) {
+  RowT<M> t;
+  if constexpr (M >= 1 && M <= 4) {
+    // (explicit multiply-adds: the library is built with -ffp-contract=off)
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      t.a[m] = fma(f.yu[m][0], r.b, fma(f.yd[m][0], r.a, f.yl[m][0] * r.w));
+      t.b[m] = fma(f.yu[m][1], r.e, fma(f.yd[m][1], r.b, f.yl[m][1] * r.a));
+    }
+  } else {
+    t.a[0] = t.b[0] = 0.0;  // (the identity and the 5-point forms work on the rows themselves)
+  }
+  return t;
+}
+
+// (Op v) at (i, j) and (i, j+1) from the rows above / at / below (n, c, s) and their transforms; M == 0: the identity
+template <int M>
+__device__ __forceinline__ void apply2(const KOp& op, const Fac<M>& f, long i, const Row4& n, const Row4& c, const Row4& s, const RowT<M>& tn,
+                                       const RowT<M>& tc, const RowT<M>& ts, double& ra, double& rb) {
   if (M == 0) {
     ra = c.a;
     rb = c.b;
@@ -90,31 +119,17 @@ __device__ __forceinline__ void apply2(const KOp& op, const Fac<M>& f, long i, c
     rb = fma(db, c.b, fma(op.cn, n.b + s.b, op.cw * (c.a + c.e)));
     return;
   }
-  // (explicit multiply-adds: the library is built with -ffp-contract=off, and on the Galerkin levels — every term a full
-  // 9-point stencil, M too — these passes are bound by the vector ALUs, not by memory)
-  double offa = 0.0, offb = 0.0, da = 0.0, db = 0.0;
+  double va = 0.0, vb = 0.0;
   constexpr int TERMS = M < kFive ? M : 0;
 #pragma unroll
   for (int m = 0; m < TERMS; ++m) {
     const double* X = op.X[m] + i;
     const double xl = X[0], xd = X[op.ldx], xu = X[2 * op.ldx];
-    {
-      const double rn = fma(f.yu[m][0], n.b, fma(f.yd[m][0], n.a, f.yl[m][0] * n.w));
-      const double rc = fma(f.yu[m][0], c.b, f.yl[m][0] * c.w);
-      const double rs = fma(f.yu[m][0], s.b, fma(f.yd[m][0], s.a, f.yl[m][0] * s.w));
-      offa = fma(xu, rs, fma(xd, rc, fma(xl, rn, offa)));
-      da = fma(xd, f.yd[m][0], da);
-    }
-    {
-      const double rn = fma(f.yu[m][1], n.e, fma(f.yd[m][1], n.b, f.yl[m][1] * n.a));
-      const double rc = fma(f.yu[m][1], c.e, f.yl[m][1] * c.a);
-      const double rs = fma(f.yu[m][1], s.e, fma(f.yd[m][1], s.b, f.yl[m][1] * s.a));
-      offb = fma(xu, rs, fma(xd, rc, fma(xl, rn, offb)));
-      db = fma(xd, f.yd[m][1], db);
-    }
+    va = fma(xu, ts.a[m], fma(xd, tc.a[m], fma(xl, tn.a[m], va)));
+    vb = fma(xu, ts.b[m], fma(xd, tc.b[m], fma(xl, tn.b[m], vb)));
   }
-  ra = fma(da, c.a, offa);
-  rb = fma(db, c.b, offb);
+  ra = va;
+  rb = vb;
 }
 
 constexpr int kRqThreads = 256;
@@ -192,15 +207,19 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass1(KGrid g, KOp A, KOp Mo,
     auto loadp = [&](long i) { return init == 1 ? zero : load4(gv, po, -1.0, beta, i, nc, j, jw, je, hw, he); };
     Row4 xn = load4(x, nullptr, 1.0, 0.0, i0 - 1, nc, j, jw, je, hw, he), xc = load4(x, nullptr, 1.0, 0.0, i0, nc, j, jw, je, hw, he);
     Row4 pn = loadp(i0 - 1), pc = loadp(i0);
+    RowT<MA> axn = transform<MA>(fa, xn), axc = transform<MA>(fa, xc), apn = transform<MA>(fa, pn), apc = transform<MA>(fa, pc);
+    RowT<MM> mxn = transform<MM>(fm, xn), mxc = transform<MM>(fm, xc), mpn = transform<MM>(fm, pn), mpc = transform<MM>(fm, pc);
 #pragma unroll 2
     for (long i = i0; i < i1; ++i) {
       const Row4 xs = load4(x, nullptr, 1.0, 0.0, i + 1, nc, j, jw, je, hw, he);
       const Row4 ps = loadp(i + 1);
+      const RowT<MA> axs = transform<MA>(fa, xs), aps = transform<MA>(fa, ps);
+      const RowT<MM> mxs = transform<MM>(fm, xs), mps = transform<MM>(fm, ps);
       double axa, axb, apa, apb, mxa, mxb, mpa, mpb;
-      apply2<MA>(A, fa, i, xn, xc, xs, axa, axb);
-      apply2<MA>(A, fa, i, pn, pc, ps, apa, apb);
-      apply2<MM>(Mo, fm, i, xn, xc, xs, mxa, mxb);
-      apply2<MM>(Mo, fm, i, pn, pc, ps, mpa, mpb);
+      apply2<MA>(A, fa, i, xn, xc, xs, axn, axc, axs, axa, axb);
+      apply2<MA>(A, fa, i, pn, pc, ps, apn, apc, aps, apa, apb);
+      apply2<MM>(Mo, fm, i, xn, xc, xs, mxn, mxc, mxs, mxa, mxb);
+      apply2<MM>(Mo, fm, i, pn, pc, ps, mpn, mpc, mps, mpa, mpb);
       acc[kS_xAx] = fma(xc.b, axb, fma(xc.a, axa, acc[kS_xAx]));
       acc[kS_xAp] = fma(xc.b, apb, fma(xc.a, apa, acc[kS_xAp]));
       acc[kS_pAx] = fma(pc.b, axb, fma(pc.a, axa, acc[kS_pAx]));
@@ -214,6 +233,14 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass1(KGrid g, KOp A, KOp Mo,
       xc = xs;
       pn = pc;
       pc = ps;
+      axn = axc;
+      axc = axs;
+      apn = apc;
+      apc = aps;
+      mxn = mxc;
+      mxc = mxs;
+      mpn = mpc;
+      mpc = mps;
     }
   }
   block_partials<kRqSums>(acc, s_part, partials, nblocks, (int)(blockIdx.y * gridDim.x + blockIdx.x));
@@ -239,12 +266,16 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2(KGrid g, KOp A, KOp Mo,
     load_fac<MM>(Mo, j, fm);
     const double* pp = init == 1 ? nullptr : p;
     Row4 xn = load4(x, pp, 1.0, delta, i0 - 1, nc, j, jw, je, hw, he), xc = load4(x, pp, 1.0, delta, i0, nc, j, jw, je, hw, he);
+    RowT<MA> axn = transform<MA>(fa, xn), axc = transform<MA>(fa, xc);
+    RowT<MM> mxn = transform<MM>(fm, xn), mxc = transform<MM>(fm, xc);
 #pragma unroll 2
     for (long i = i0; i < i1; ++i) {
       const Row4 xs = load4(x, pp, 1.0, delta, i + 1, nc, j, jw, je, hw, he);
+      const RowT<MA> axs = transform<MA>(fa, xs);
+      const RowT<MM> mxs = transform<MM>(fm, xs);
       double axa, axb, mxa, mxb;
-      apply2<MA>(A, fa, i, xn, xc, xs, axa, axb);
-      apply2<MM>(Mo, fm, i, xn, xc, xs, mxa, mxb);
+      apply2<MA>(A, fa, i, xn, xc, xs, axn, axc, axs, axa, axb);
+      apply2<MM>(Mo, fm, i, xn, xc, xs, mxn, mxc, mxs, mxa, mxb);
       const double ga = 2.0 * (axa - rho * mxa), gb = 2.0 * (axb - rho * mxb);
       if (init != 1) *reinterpret_cast<double2*>(xnew + i * nc + j) = make_double2(xc.a, xc.b);  // (the initial pair: x' = x stays where it is)
       *reinterpret_cast<double2*>(gout + i * nc + j) = make_double2(ga, gb);
@@ -253,6 +284,10 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2(KGrid g, KOp A, KOp Mo,
       acc[2] = fma(gb, gb, fma(ga, ga, acc[2]));
       xn = xc;
       xc = xs;
+      axn = axc;
+      axc = axs;
+      mxn = mxc;
+      mxc = mxs;
     }
   }
   block_partials<3>(acc, s_part, partials, nblocks, (int)(blockIdx.y * gridDim.x + blockIdx.x));
@@ -273,14 +308,18 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_gmg(KGrid g, KOp Mo, const do
     Fac<MM> fm;
     load_fac<MM>(Mo, j, fm);
     Row4 gn = load4(gv, nullptr, 1.0, 0.0, i0 - 1, nc, j, jw, je, hw, he), gc = load4(gv, nullptr, 1.0, 0.0, i0, nc, j, jw, je, hw, he);
+    RowT<MM> tn = transform<MM>(fm, gn), tc = transform<MM>(fm, gc);
 #pragma unroll 2
     for (long i = i0; i < i1; ++i) {
       const Row4 gs = load4(gv, nullptr, 1.0, 0.0, i + 1, nc, j, jw, je, hw, he);
+      const RowT<MM> ts = transform<MM>(fm, gs);
       double ma, mb;
-      apply2<MM>(Mo, fm, i, gn, gc, gs, ma, mb);
+      apply2<MM>(Mo, fm, i, gn, gc, gs, tn, tc, ts, ma, mb);
       acc[0] = fma(gc.b, mb, fma(gc.a, ma, acc[0]));
       gn = gc;
       gc = gs;
+      tn = tc;
+      tc = ts;
     }
   }
   block_partials<1>(acc, s_part, partials + 3L * nblocks, nblocks, (int)(blockIdx.y * gridDim.x + blockIdx.x));
@@ -367,17 +406,44 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass2_point(KGrid g, KOp A, K
 
 // ---- scalars --------------------------------------------------------------------------------------------------
 
-// results' per-block partial sums -> s_out[q]: one wave per result (lane-strided, then a fixed shuffle tree); the block
-// has at least nq waves
+// results' per-block partial sums -> s_out[q] (q < nq <= 8), by a block of kScalarThreads.  The sums of a big level's
+// pass are 4096 per result, fresh in HBM: a wave per result adding them up lane-strided is a chain of dependent
+// ~2 us loads (measured 20 - 27 us per scalar kernel behind the 8192^2 and 4096^2 passes, 0.5 ms of an 8.2 ms cycle).
+// Here the waves split each result between them and a lane issues ALL its loads before it adds the first: one memory
+// latency.  Fixed order of additions for a given number of blocks (lane-strided, shuffle tree, pieces in order).
+constexpr int kScalarThreads = 1024;
+constexpr int kScalarDepth = 16;  // loads in flight per lane: 16 waves x 64 lanes x 16 = 16384 = 4 results of 4096 sums
 __device__ __forceinline__ void reduce_results(const double* __restrict__ partials, int nblocks, int nq, double* s_out) {
+  __shared__ double s_piece[kRqSums][kScalarThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave < nq) {
-    const double* src = partials + (long)wave * nblocks;
+  constexpr int nwaves = kScalarThreads / 64;
+  const int slots = nq <= 4 ? 4 : kRqSums;  // results, padded to a divisor of the waves
+  const int per = nwaves / slots;           // waves per result
+  const int q = wave % slots, piece = wave / slots;
+  const int span = ((nblocks + per - 1) / per + 63) & ~63;  // sums per wave: whole rounds of the lanes
+  {
+    const double* src = partials + (long)(q < nq ? q : 0) * nblocks;
+    const int lo = piece * span, hi = q >= nq ? 0 : (lo + span < nblocks ? lo + span : nblocks);  // (a wave without a result: nothing)
     double acc = 0.0;
-    for (int i = lane; i < nblocks; i += 64) acc += src[i];
+    for (int base = lo + lane; base < hi; base += 64 * kScalarDepth) {
+      double v[kScalarDepth];
+#pragma unroll
+      for (int k = 0; k < kScalarDepth; ++k) {
+        const int idx = base + 64 * k;
+        v[k] = idx < hi ? src[idx] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < kScalarDepth; ++k) acc += v[k];
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
-    if (lane == 0) s_out[wave] = acc;
+    if (lane == 0 && q < nq) s_piece[q][piece] = acc;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nq) {
+    double t = 0.0;
+    for (int k = 0; k < per; ++k) t += s_piece[threadIdx.x][k];
+    s_out[threadIdx.x] = t;
   }
   __syncthreads();
 }
@@ -438,7 +504,7 @@ __device__ void rq_step_scalars(const double* s, double* __restrict__ state, int
 }
 
 
-__global__ void __launch_bounds__(64 * kRqSums) k_rq_scalars1(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int init,
+__global__ void __launch_bounds__(kScalarThreads) k_rq_scalars1(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int init,
                                                            int robust) {
   __shared__ double s[kRqSums];
   reduce_results(partials, nblocks, kRqSums, s);
@@ -462,7 +528,7 @@ __device__ void rq_gradient_scalars(const double* s, double gmg_in, double* __re
 }
 
 
-__global__ void __launch_bounds__(256) k_rq_scalars2(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int m_identity,
+__global__ void __launch_bounds__(kScalarThreads) k_rq_scalars2(const double* __restrict__ partials, int nblocks, double* __restrict__ state, int m_identity,
                                                            int init) {
   __shared__ double s[4];
   reduce_results(partials, nblocks, m_identity == 2 ? 4 : 3, s);  // m_identity == 2: <g, M g> is result 3 of the partial sums (k_rq_gmg)
@@ -646,7 +712,7 @@ void launch_rq_pass1(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, cons
     nblocks = (int)blocks;
     hipLaunchKernelGGL(k_rq_pass1_point, dim3((unsigned)blocks), dim3(kRqThreads), 0, s, g, A, Mo, m_identity, x, gv, pold, pnew, state, init, partials, nblocks);
   }
-  hipLaunchKernelGGL(k_rq_scalars1, dim3(1), dim3(64 * kRqSums), 0, s, partials, nblocks, state, init, robust);
+  hipLaunchKernelGGL(k_rq_scalars1, dim3(1), dim3(kScalarThreads), 0, s, partials, nblocks, state, init, robust);
 }
 
 // pass 2 without its scalars (the caller may have to put <g, M g> into the state first)
@@ -700,7 +766,7 @@ bool launch_rq_gmg(hipStream_t s, KGrid g, KOp Mo, const double* gv, double* par
 }
 
 void launch_rq_scalars2(hipStream_t s, const double* partials, int nblocks, double* state, int m_identity, int init) {
-  hipLaunchKernelGGL(k_rq_scalars2, dim3(1), dim3(256), 0, s, partials, nblocks, state, m_identity, init);
+  hipLaunchKernelGGL(k_rq_scalars2, dim3(1), dim3(kScalarThreads), 0, s, partials, nblocks, state, m_identity, init);
 }
 
 // the whole call in one launch where the level is small enough (k_rq_small): x holds start vector and result, p and gv
