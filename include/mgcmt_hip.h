@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MGCMT_ABI_VERSION 5
+#define MGCMT_ABI_VERSION 6
 #define MGCMT_MAX_TERMS 4
 #define MGCMT_HALO_ROWS 16 /* rows of halo kept above and below every vector of a 2-D level (a 1-D level keeps one: its
                               "row" is the whole vector); how many of them a sharded cycle fills: mgcmt_plan_level_halo */
@@ -180,6 +180,18 @@ int mgcmt_ritz_pair(mgcmt_plan* plan, int level, int x_slot, int x_vec, int w_sl
  * infinities (the repaired variants).  rho_out (may be NULL: nothing synchronises then): the Rayleigh quotient of the
  * result (:53). */
 int mgcmt_rqmin(mgcmt_plan* plan, int level, int slot, const int* vecs, int nu, int robust, double* rho_out, void* stream);
+/* One line minimisation of the Rayleigh quotient of the plan's pair (A, M) on `level` along a direction the caller
+ * supplies: the 2 x 2 problem of rqmin (MGCMTSolver.py:33-50) on span{x, w} — x_out = x + delta w — followed by
+ * g = 2 (A x_out - rho M x_out) (:52-54), both on the device, the state words of mgcmt_rqmin reused; no host round trip.
+ * With w the preconditioned residual (a V-cycle applied to g) this is the iteration of the 2-D square-well driver.
+ * Vectors are {slot, vec} pairs, all distinct: x (read), w (read; NULL: only rho and g of x are computed, x_out unused),
+ * x_out, g, and, with a non-identity mass operator, a work vector (NULL otherwise).  record >= 0: the Rayleigh quotient
+ * of x_out is also stored as number `record` (< MGCMT_RQ_HISTORY) of the plan's device-side history, read back — with
+ * the only synchronisation — by mgcmt_rq_history. */
+#define MGCMT_RQ_HISTORY 4096
+int mgcmt_rq_line_step(mgcmt_plan* plan, int level, const int* x, const int* w, const int* x_out, const int* g, const int* work, int robust,
+                       int record, void* stream);
+int mgcmt_rq_history(mgcmt_plan* plan, int first, int count, double* out, void* stream);
 /* vcycle_rqmg (MGCMTSolver.py:99-122) from the finest level: rqmin with nu1 steps, the iterate restricted (:113), the same on
  * the Galerkin pair (R A P, R M P) of every coarser level of the plan (the coarsest one only minimises), the interpolated
  * coarse iterates added on the way up (:116-118) and nu2 more steps per level; vectors as for mgcmt_rqmin, on every level.

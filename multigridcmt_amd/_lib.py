@@ -17,9 +17,10 @@ WJACOBI, GS_LEX, SOR_LEX, GS_MC = 0, 1, 2, 3
 SLOT_V, SLOT_F, SLOT_T, SLOT_W = 0, 1, 2, 3
 OP_A, OP_M = 0, 1
 HALO_ROWS = 16         # 2-D levels (a 1-D level keeps one halo "row"); exchanged rows per level: Plan.level_halo
+RQ_HISTORY = 4096      # MGCMT_RQ_HISTORY: Rayleigh quotients Plan.rq_line_step can record on the device
 MAX_TERMS = 4
 MAX_VEC = 32
-ABI_VERSION = 5
+ABI_VERSION = 6
 OPT_FUSED = 0
 OPT_FUSED_ROWS = 1
 OPT_TAIL = 4
@@ -97,6 +98,8 @@ _SIGNATURES = {
     "mgcmt_ritz_pair": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _dp, c_void_p]),
     "mgcmt_rqmin": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, _dp, c_void_p]),
     "mgcmt_vcycle_rqmg": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _dp, c_void_p]),
+    "mgcmt_rq_line_step": (c_int, [c_void_p, c_int] + [ctypes.POINTER(c_int)] * 5 + [c_int, c_int, c_void_p]),
+    "mgcmt_rq_history": (c_int, [c_void_p, c_int, c_int, _dp, c_void_p]),
     "mgcmt_lincomb": (c_int, [c_void_p, c_int, c_int, _dp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_void_p]),
     "mgcmt_scale": (c_int, [c_void_p, c_int, c_double, c_int, c_int, c_void_p]),
     "mgcmt_block_gram": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int), c_int, POINTER(c_int), POINTER(c_int),

@@ -198,13 +198,14 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass1(KGrid g, KOp A, KOp Mo,
     const bool hw = j > 0, he = j + 2 < nc;
     const long jw = hw ? j - 1 : j, je = he ? j + 2 : j + 1;
     const double beta = init ? 0.0 : state[kBeta];
-    const double* po = init == 2 ? nullptr : pold;  // the first step takes p = -g (MGCMTSolver.py:29-30): p_old is not read
+    const double* po = init >= 2 ? nullptr : pold;  // the first step takes p = -g (MGCMTSolver.py:29-30): p_old is not read
     Fac<MA> fa;
     Fac<MM> fm;
     load_fac<MA>(A, j, fa);
     load_fac<MM>(Mo, j, fm);
     const Row4 zero{0.0, 0.0, 0.0, 0.0};
-    auto loadp = [&](long i) { return init == 1 ? zero : load4(gv, po, -1.0, beta, i, nc, j, jw, je, hw, he); };
+    const double cg = init == 3 ? 1.0 : -1.0;  // (init 3: the direction is gv itself, mgcmt_rq_line_step)
+    auto loadp = [&](long i) { return init == 1 ? zero : load4(gv, po, cg, beta, i, nc, j, jw, je, hw, he); };
     Row4 xn = load4(x, nullptr, 1.0, 0.0, i0 - 1, nc, j, jw, je, hw, he), xc = load4(x, nullptr, 1.0, 0.0, i0, nc, j, jw, je, hw, he);
     Row4 pn = loadp(i0 - 1), pc = loadp(i0);
     RowT<MA> axn = transform<MA>(fa, xn), axc = transform<MA>(fa, xc), apn = transform<MA>(fa, pn), apc = transform<MA>(fa, pc);
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass1(KGrid g, KOp A, KOp Mo,
       acc[kS_xMp] = fma(xc.b, mpb, fma(xc.a, mpa, acc[kS_xMp]));
       acc[kS_pMx] = fma(pc.b, mxb, fma(pc.a, mxa, acc[kS_pMx]));
       acc[kS_pMp] = fma(pc.b, mpb, fma(pc.a, mpa, acc[kS_pMp]));
-      if (init != 1) *reinterpret_cast<double2*>(pnew + i * nc + j) = make_double2(pc.a, pc.b);
+      if (init == 0 || init == 2) *reinterpret_cast<double2*>(pnew + i * nc + j) = make_double2(pc.a, pc.b);
       xn = xc;
       xc = xs;
       pn = pc;
@@ -364,11 +365,12 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass1_point(KGrid g, KOp A, K
   for (int q = 0; q < kRqSums; ++q) acc[q] = 0.0;
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
     const long i = k / g.nc, j = k - i * g.nc;
-    const double* po = init == 2 ? nullptr : pold;
-    const double xc = x[k], pc = init == 1 ? 0.0 : (po ? -gv[k] + beta * po[k] : -gv[k]);
+    const double* po = init >= 2 ? nullptr : pold;
+    const double cg = init == 3 ? 1.0 : -1.0;
+    const double xc = x[k], pc = init == 1 ? 0.0 : (po ? -gv[k] + beta * po[k] : cg * gv[k]);
     const double ax = apply_point(A, 0, x, nullptr, 1.0, 0.0, g.nc, i, j), mx = apply_point(Mo, m_identity, x, nullptr, 1.0, 0.0, g.nc, i, j);
-    const double ap = init == 1 ? 0.0 : apply_point(A, 0, gv, po, -1.0, beta, g.nc, i, j);
-    const double mp = init == 1 ? 0.0 : apply_point(Mo, m_identity, gv, po, -1.0, beta, g.nc, i, j);
+    const double ap = init == 1 ? 0.0 : apply_point(A, 0, gv, po, cg, beta, g.nc, i, j);
+    const double mp = init == 1 ? 0.0 : apply_point(Mo, m_identity, gv, po, cg, beta, g.nc, i, j);
     acc[kS_xAx] += xc * ax;
     acc[kS_xAp] += xc * ap;
     acc[kS_pAx] += pc * ax;
@@ -377,7 +379,7 @@ __global__ void __launch_bounds__(kRqThreads) k_rq_pass1_point(KGrid g, KOp A, K
     acc[kS_xMp] += xc * mp;
     acc[kS_pMx] += pc * mx;
     acc[kS_pMp] += pc * mp;
-    if (init != 1) pnew[k] = pc;
+    if (init == 0 || init == 2) pnew[k] = pc;
   }
   block_partials<kRqSums>(acc, s_part, partials, nblocks, (int)blockIdx.x);
 }
@@ -667,6 +669,21 @@ int operator_form(const KOp& A) {
   return A.nterms < 1 ? 1 : (A.nterms > 4 ? 4 : A.nterms);
 }
 
+// rows per block of a march: 32 on big levels (two overlap rows per chunk: 6 % more loads); shorter chunks where the level
+// would otherwise not fill the chip — a block's march is one dependent load per row step, ~1 us each (measured: 29 - 50 us
+// per pass on every level from 64^2 to 2048^2 with 32-row chunks).  At most 4096 blocks: the partial sums' array.
+long march_rows(const KGrid& g, unsigned gx) {
+  static const long min_blocks = [] {  // (MGCMT_RQ_MIN_BLOCKS: A/B measurements)
+    const char* e = getenv("MGCMT_RQ_MIN_BLOCKS");
+    const long v = e ? atol(e) : 0;
+    return v > 0 && v <= 4096 ? v : 2048L;
+  }();
+  long rows = 32;
+  while ((long)gx * ((g.nr + rows - 1) / rows) > 4096) rows *= 2;
+  while (rows > 2 && (long)gx * ((g.nr + rows - 1) / rows) < min_blocks) rows /= 2;
+  return rows;
+}
+
 bool march_ok(const KGrid& g, const KOp& A, const KOp& Mo, int m_identity, const double* a, const double* b, const double* c, const double* d,
               const double* e) {
   const uintptr_t all = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e;
@@ -687,12 +704,7 @@ void launch_rq_pass1(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, cons
   if (march_ok(g, A, Mo, m_identity, x, gv, pold, pnew, x)) {
     const dim3 b(g.nc >= 512 ? kRqThreads : 64, 1, 1);
     const unsigned gx = (unsigned)((g.nc / 2 + b.x - 1) / b.x);
-    // rows per block: 32 on big levels (two overlap rows per chunk: 6 % more loads); shorter chunks where the level would
-    // otherwise not fill the chip — a block's march is one dependent load per row step, ~1 us each (measured: 29 - 50 us
-    // per pass on every level from 64^2 to 2048^2 with 32-row chunks)
-    long rows = 32;
-    while ((long)gx * ((g.nr + rows - 1) / rows) > 4096) rows *= 2;
-    while (rows > 2 && (long)gx * ((g.nr + rows - 1) / rows) < 2048) rows /= 2;
+    const long rows = march_rows(g, gx);
     const dim3 grid(gx, (unsigned)((g.nr + rows - 1) / rows), 1);
     nblocks = (int)(grid.x * grid.y);
     const int mm = m_identity ? 0 : 1;
@@ -722,12 +734,7 @@ int launch_rq_pass2(hipStream_t s, KGrid g, KOp A, KOp Mo, int m_identity, const
   if (march_ok(g, A, Mo, m_identity, x, p, xnew, gout, x)) {
     const dim3 b(g.nc >= 512 ? kRqThreads : 64, 1, 1);
     const unsigned gx = (unsigned)((g.nc / 2 + b.x - 1) / b.x);
-    // rows per block: 32 on big levels (two overlap rows per chunk: 6 % more loads); shorter chunks where the level would
-    // otherwise not fill the chip — a block's march is one dependent load per row step, ~1 us each (measured: 29 - 50 us
-    // per pass on every level from 64^2 to 2048^2 with 32-row chunks)
-    long rows = 32;
-    while ((long)gx * ((g.nr + rows - 1) / rows) > 4096) rows *= 2;
-    while (rows > 2 && (long)gx * ((g.nr + rows - 1) / rows) < 2048) rows /= 2;
+    const long rows = march_rows(g, gx);
     const dim3 grid(gx, (unsigned)((g.nr + rows - 1) / rows), 1);
     nblocks = (int)(grid.x * grid.y);
     const int mm = m_identity ? 0 : 1;
@@ -756,9 +763,7 @@ bool launch_rq_gmg(hipStream_t s, KGrid g, KOp Mo, const double* gv, double* par
   if (!(g.coarsen_rows && g.nr >= 2 && g.nc >= 2 && (g.nc & 1) == 0 && (((uintptr_t)gv) & 15) == 0 && Mo.nterms == 1)) return false;
   const dim3 b(g.nc >= 512 ? kRqThreads : 64, 1, 1);
   const unsigned gx = (unsigned)((g.nc / 2 + b.x - 1) / b.x);
-  long rows = 32;
-  while ((long)gx * ((g.nr + rows - 1) / rows) > 4096) rows *= 2;
-  while (rows > 2 && (long)gx * ((g.nr + rows - 1) / rows) < 2048) rows /= 2;
+  const long rows = march_rows(g, gx);
   const dim3 grid(gx, (unsigned)((g.nr + rows - 1) / rows), 1);
   if ((int)(grid.x * grid.y) != nblocks) return false;  // (pass 2 took the point form: another block count)
   hipLaunchKernelGGL((k_rq_gmg<1>), grid, b, 0, s, g, Mo, gv, (int)rows, partials, nblocks);

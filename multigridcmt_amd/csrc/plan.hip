@@ -918,6 +918,7 @@ int mgcmt_plan_destroy(mgcmt_plan* p) {
   if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
   if (p->d_rq) (void)hipFree(p->d_rq);
   if (p->d_rqstate) (void)hipFree(p->d_rqstate);
+  if (p->d_rqhistory) (void)hipFree(p->d_rqhistory);
   if (p->tailmat.mt) (void)hipFree(p->tailmat.mt);
   if (p->lex_carry) (void)hipFree(p->lex_carry);
   if (p->lex_sync) (void)hipFree(p->lex_sync);
@@ -1291,19 +1292,22 @@ static int rqmin_check(mgcmt_plan* p, int l, int slot, const int* vecs, int nu) 
   return MGCMT_OK;
 }
 
+// M: the plan's mass operator; none, or one whose factors are identities, is the identity (no application at all)
+static bool mass_is_identity(const mgcmt_plan* p, int l) {
+  if (!p->has_mass) return true;
+  const Level& L = p->levels[l];
+  auto is_identity = [](const Tri& t) {
+    for (int64_t i = 0; i < t.n; ++i)
+      if (t.di(i) != 1.0 || (i > 0 && t.lo(i) != 0.0) || (i + 1 < t.n && t.up(i) != 0.0)) return false;
+    return true;
+  };
+  return L.hM.nterms == 1 && is_identity(L.hM.X[0]) && is_identity(L.hM.Y[0]);
+}
+
 static int rqmin_impl(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, int robust, hipStream_t s) {
   const Level& L = p->levels[l];
   const KOp& A = L.dA.k;
-  // M: the plan's mass operator; none, or one whose factors are identities, is the identity (no application at all)
-  bool m_identity = !p->has_mass;
-  if (p->has_mass) {
-    auto is_identity = [](const Tri& t) {
-      for (int64_t i = 0; i < t.n; ++i)
-        if (t.di(i) != 1.0 || (i > 0 && t.lo(i) != 0.0) || (i + 1 < t.n && t.up(i) != 0.0)) return false;
-      return true;
-    };
-    m_identity = L.hM.nterms == 1 && is_identity(L.hM.X[0]) && is_identity(L.hM.Y[0]);
-  }
+  const bool m_identity = mass_is_identity(p, l);
   const KOp& Mo = p->has_mass ? L.dM.k : A;  // (not read when M is the identity)
   const KGrid g = p->kgrid(l);
   double* x = p->kvec(l, slot, vecs[0]).p;
@@ -1355,6 +1359,69 @@ int mgcmt_rqmin(mgcmt_plan* p, int l, int slot, const int* vecs, int nu, int rob
   MG_TRY(rqmin_check(p, l, slot, vecs, nu));
   MG_TRY(rqmin_impl(p, l, slot, vecs, nu, robust, S(stream)));
   return rq_result(p, rho_out, S(stream));
+}
+
+// One line minimisation of the Rayleigh quotient along a direction the CALLER supplies (see mgcmt_hip.h): the passes of
+// rqmin with p = w read as it is and not stored, then x' = x + delta w and its gradient.
+int mgcmt_rq_line_step(mgcmt_plan* p, int l, const int* xv, const int* wv, const int* xoutv, const int* gv, const int* tmpv, int robust, int record,
+                       void* stream) {
+  MG_TRY(check_level(p, l));
+  if (!xv || !gv) return fail(MGCMT_ERR_INVALID, "rq_line_step: x and g are required");
+  if (wv && !xoutv) return fail(MGCMT_ERR_INVALID, "rq_line_step: a step needs a vector for x + delta w");
+  const int* all[5] = {xv, wv, xoutv, gv, tmpv};
+  for (int a = 0; a < 5; ++a) {
+    if (!all[a]) continue;
+    MG_TRY(check_vec(p, l, all[a][0], all[a][1]));
+    MG_TRY(ensure_slot(p, l, all[a][0]));
+    for (int b = 0; b < a; ++b)
+      if (all[b] && all[a][0] == all[b][0] && all[a][1] == all[b][1]) return fail(MGCMT_ERR_INVALID, "rq_line_step: the vectors must be distinct");
+  }
+  if (record >= MGCMT_RQ_HISTORY) return fail(MGCMT_ERR_INVALID, "rq_line_step: history index out of range");
+  if (!p->d_rqstate) {
+    MG_HIP(hipMalloc((void**)&p->d_rqstate, sizeof(double) * rq_state_words()));
+    MG_HIP(hipMemset(p->d_rqstate, 0, sizeof(double) * rq_state_words()));
+  }
+  if (record >= 0 && !p->d_rqhistory) MG_HIP(hipMalloc((void**)&p->d_rqhistory, sizeof(double) * MGCMT_RQ_HISTORY));
+  hipStream_t s = S(stream);
+  const Level& L = p->levels[l];
+  const KOp& A = L.dA.k;
+  const bool m_identity = mass_is_identity(p, l);
+  if (!m_identity && !tmpv) return fail(MGCMT_ERR_INVALID, "rq_line_step: with a mass operator a work vector (for M g) is required");
+  const KOp& Mo = p->has_mass ? L.dM.k : A;
+  const KGrid g = p->kgrid(l);
+  const double* x = p->kvec(l, xv[0], xv[1]).p;
+  const double* w = wv ? p->kvec(l, wv[0], wv[1]).p : nullptr;
+  double* xout = xoutv ? p->kvec(l, xoutv[0], xoutv[1]).p : nullptr;
+  double* gout = p->kvec(l, gv[0], gv[1]).p;
+  double* st = p->d_rqstate;
+  double* part = p->d_partials;
+  // without a direction: the initial pair of rqmin (rho and g of x); with one: pass 1 reads p = w (init 3), pass 2 is a step's
+  const int init1 = w ? 3 : 1, init2 = w ? 0 : 1;
+  launch_rq_pass1(s, g, A, Mo, m_identity ? 1 : 0, x, w, nullptr, nullptr, st, init1, robust, part);
+  const int nb = launch_rq_pass2(s, g, A, Mo, m_identity ? 1 : 0, x, w, xout, gout, st, init2, part);
+  int mflag = m_identity ? 1 : 0;
+  if (!m_identity) {
+    if (launch_rq_gmg(s, g, Mo, gout, part, nb)) {
+      mflag = 2;
+    } else {
+      double* tmp = p->kvec(l, tmpv[0], tmpv[1]).p;
+      launch_apply(s, g, Mo, KVec{gout, 0}, KVec{tmp, 0}, p->d_zero, 1);
+      launch_dots(s, p->interior(l), gout, tmp, 0, 1, p->d_partials + 40000, st + rq_word_gmg());
+    }
+  }
+  launch_rq_scalars2(s, part, nb, st, mflag, init2);
+  MG_TRY(post_launch());
+  if (record >= 0) MG_HIP(hipMemcpyAsync(p->d_rqhistory + record, st + rq_word_rho(), sizeof(double), hipMemcpyDeviceToDevice, s));
+  return MGCMT_OK;
+}
+
+int mgcmt_rq_history(mgcmt_plan* p, int first, int count, double* out, void* stream) {
+  if (!p || !out || first < 0 || count < 0 || first + count > MGCMT_RQ_HISTORY) return fail(MGCMT_ERR_INVALID, "rq_history: bad range");
+  if (count == 0) return MGCMT_OK;
+  if (!p->d_rqhistory) return fail(MGCMT_ERR_INVALID, "rq_history: nothing recorded");
+  MG_HIP(hipMemcpyAsync(out, p->d_rqhistory + first, sizeof(double) * count, hipMemcpyDeviceToHost, S(stream)));
+  MG_HIP(hipStreamSynchronize(S(stream)));
+  return MGCMT_OK;
 }
 
 // vcycle_rqmg (MGCMTSolver.py:99-122): rqmin, the ITERATE restricted (:113), the recursion on the Galerkin pair (R A P,

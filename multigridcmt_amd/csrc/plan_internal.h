@@ -70,6 +70,7 @@ struct mgcmt_plan {
   double* d_scalars = nullptr;  // [4*kMaxVec] reduction results
   double* d_rq = nullptr;       // Gram results of mgcmt_rayleigh_residual, one block per column
   double* d_rqstate = nullptr;  // scalars of the device-resident Rayleigh-quotient minimisation (kernels_rq.hip)
+  double* d_rqhistory = nullptr;  // Rayleigh quotients recorded by mgcmt_rq_line_step (MGCMT_RQ_HISTORY numbers)
   std::vector<double> h_shifts;
   bool has_mass = false;
   bool use_fused = true;

@@ -211,13 +211,14 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
 
     method="rqmg"    ``cycles`` sweeps of MGCMTSolver.vcycle_rqmg (RQMin.py:25-27 with the 2-D transfers).
     method="vcycle"  Rayleigh-quotient minimisation with a V-cycle preconditioner: every iteration applies one V(nu,nu)
-                     cycle of H (from a zero start) to the eigen-residual r = H x - rho x and minimises the Rayleigh
-                     quotient over span{x, w} — the 2x2 problem of rqmin (MGCMTSolver.py:44-50) with the
-                     preconditioned residual as the search direction.  All vector work stays in HBM: per iteration
-                     one V-cycle from a zero start (a flag: V is neither cleared nor read), one operator application (a
-                     row march that forms H w in registers and reduces the five inner products of the 2x2 problem without
-                     storing it), the update of x in place and ONE shifted application for the new eigen-residual
-                     (H - rho I) x: 7 vector passes' worth of traffic per iteration beside the cycle.
+                     cycle of H (from a zero start) to the gradient g = 2 (H x - rho x) and minimises the Rayleigh
+                     quotient over span{x, w} — the 2x2 problem of rqmin (MGCMTSolver.py:33-50) with the
+                     preconditioned gradient as the search direction — by the two passes of the device-resident rqmin
+                     (Plan.rq_line_step: the eight inner products with H w formed in registers, the pencil solved on
+                     the device, then x + delta w and its gradient in one pass).  Per iteration: one V-cycle from a zero
+                     start (a flag: V is neither cleared nor read) and 48 B per point of vector traffic beside it;
+                     nothing comes back to the host inside the loop (the Rayleigh quotients are recorded on the
+                     device and fetched once).
     Returns (rho, x); ``history`` (a list) receives rho after every cycle, ``stats`` (a dict) the seconds spent in
     the iteration loop alone (start vector generation and the host transfers excluded)."""
     from . import _lib
@@ -241,43 +242,45 @@ def potential_well_eigensolve(gridsize=2 ** 7, depth=50.0, inner=None, cycles=8,
         raise ValueError("method must be 'rqmg' or 'vcycle'")
     kind, omega = (_lib.GS_MC, 1.0) if smoother == "rb" else (_lib.WJACOBI, 2. / 3.)
     V, F, W = _lib.SLOT_V, _lib.SLOT_F, _lib.SLOT_W
-    # x lives in column 1, so that its eigen-residual r = (H - rho I) x is ONE operator application with the shift of
-    # column 1 (= rho) while the V-cycle on column 0 keeps the unshifted Hamiltonian (shift 0)
-    X, PW, R, SCRATCH = (W, 1), (V, 0), (F, 0), (W, 0)
+    # the iterate alternates between the two columns of slot W (x + delta w is written beside x); the V-cycle runs on
+    # column 0 with shift 0: right-hand side (F, 0) = the gradient, result (V, 0) = the search direction
+    X, XALT, PW, G = (W, 1), (W, 0), (V, 0), (F, 0)
     plan = get_plan(op, int(lowest), nvec=2)
     plan.set_shifts([0.0, 0.0])
     plan.upload(0, X[0], X[1], x0)
     plan.scale(0, 1.0 / np.sqrt(plan.dot(0, X, X)), X)
-    plan.apply(0, X, SCRATCH)
-    rho = plan.dot(0, X, SCRATCH)
-    plan.set_shifts([0.0, rho])
-    plan.apply(0, X, R, with_shift=True)                                              # r = H x - rho x
+    plan.rq_line_step(0, X, None, None, G)                                            # rho and g = 2 (H x - rho x) of the start vector
     import time
     loop_start = time.perf_counter()
     for it in range(cycles):
-        plan.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu, zero_start=True)        # w = B r  (V is not read: a flag)
-        # <x,x>, <x,w>, <w,w>, <x,H w>, <w,H w> in ONE pass over x and w (H w is formed in registers, never stored); <x,H x>
-        # is the Ritz value of the previous 2x2 problem
-        xx, xw, ww, xaw, waw = plan.ritz_pair(0, X, PW, SCRATCH)
-        xax = rho * xx
-        evals, evecs = scipy.linalg.eigh(np.array([[xax, xaw], [xaw, waw]]), np.array([[xx, xw], [xw, ww]]))
-        a, b = evecs[:, 0]
-        nrm = np.sqrt(a * a * xx + 2 * a * b * xw + b * b * ww)                       # |a x + b w|
-        plan.lincomb(0, [(a / nrm, X), (b / nrm, PW)], X)                             # x <- (a x + b w) / |a x + b w|
-        rho = float(evals[0])                                                         # = <x, H x> of the new x
-        if it + 1 < cycles:
-            plan.set_shifts([0.0, rho])
-            plan.apply(0, X, R, with_shift=True)                                      # the new eigen-residual, exactly
-        if history is not None:
-            history.append(rho)
+        if it and it % _lib.RQ_HISTORY == 0 and history is not None:
+            history.extend(plan.rq_history(0, _lib.RQ_HISTORY))
+        plan.vcycle(nu, nu, kind, omega=omega, nu_coarse=nu, zero_start=True)        # w = B g  (V is not read: a flag)
+        plan.rq_line_step(0, X, PW, XALT, G, record=it % _lib.RQ_HISTORY)             # x <- x + delta w, g <- its gradient
+        X, XALT = XALT, X
+        if it % 64 == 63:
+            # the iterate is never normalised inside the step (nothing in the 2x2 problem depends on its length); keep it
+            # of order one over long runs: x and its gradient scale together
+            scale = 1.0 / np.sqrt(plan.dot(0, X, X))
+            plan.scale(0, scale, X)
+            plan.scale(0, scale, G)
+    SCRATCH = XALT
+    if history is not None and cycles > 0:
+        history.extend(plan.rq_history(0, (cycles - 1) % _lib.RQ_HISTORY + 1))
+    else:
+        plan.sync()
     if stats is not None:
         stats["loop_seconds"] = time.perf_counter() - loop_start
     if cycles > 0:
         # what is returned is MEASURED on the returned vector — <x, H x>/<x, x> — not the running value of the 2x2 problems
         # (which the history holds; the two agree to the accuracy fp64 gives this quotient: eps * |H| / rho, 1e-10 at 8192^2)
         plan.apply(0, X, SCRATCH)
-        G = plan.gram(0, [X, SCRATCH])
-        rho = float(G[0, 1] / G[0, 0])
+        gram = plan.gram(0, [X, SCRATCH])
+        rho = float(gram[0, 1] / gram[0, 0])
+        plan.scale(0, 1.0 / np.sqrt(gram[0, 0]), X)                                    # returned with unit length
+    else:
+        plan.apply(0, X, SCRATCH)
+        rho = plan.dot(0, X, SCRATCH)
     return rho, plan.download(0, X[0], X[1])
 
 

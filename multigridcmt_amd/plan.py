@@ -201,6 +201,22 @@ class Plan:
         check(_lib.lib().mgcmt_vcycle_rqmg(self._h, slot, v, int(nu1), int(nu2), 1 if robust else 0, ctypes.byref(rho) if want_rho else None, stream))
         return rho.value if want_rho else None
 
+    def rq_line_step(self, level, x, w, x_out, g, work=None, robust=False, record=-1, stream=None):
+        """x_out = x + delta w minimising the Rayleigh quotient over span{x, w} (the 2 x 2 problem of rqmin,
+        MGCMTSolver.py:33-50) and g = 2 (A x_out - rho M x_out), on the device without a host round trip
+        (mgcmt_rq_line_step); vectors are (slot, vec) pairs.  w=None: rho and g of x alone.  record >= 0: rho is kept as
+        that entry of the device-side history (rq_history)."""
+        def pair(v):
+            return None if v is None else (ctypes.c_int * 2)(int(v[0]), int(v[1]))
+        check(_lib.lib().mgcmt_rq_line_step(self._h, level, pair(x), pair(w), pair(x_out), pair(g), pair(work), 1 if robust else 0, int(record),
+                                            stream))
+
+    def rq_history(self, first, count, stream=None):
+        """entries [first, first + count) of the Rayleigh quotients recorded by rq_line_step (one synchronisation)"""
+        out = np.empty(int(count))
+        check(_lib.lib().mgcmt_rq_history(self._h, int(first), int(count), _lib.as_dp(out), stream))
+        return out
+
     def lincomb(self, level, terms, dst, stream=None):
         """dst <- sum of coeff * (slot, vec) over `terms` = [(coeff, (slot, vec)), ...] (at most four)."""
         nt = len(terms)

@@ -183,3 +183,47 @@ def test_block_eigensolve_with_a_mass_operator(backend):
     exact = 2.0 * g ** 2 / (g + 1.0) ** 2
     five = drivers.exact_box_eigenvalues(g, "2d", 1)[0]
     assert abs(vals[0] - exact) < 0.05 * abs(five - exact)
+
+
+@pytest.mark.parametrize("with_mass", [False, True])
+def test_rq_line_step_against_the_dense_two_by_two_problem(backend, with_mass):
+    """Plan.rq_line_step (mgcmt_rq_line_step): the minimiser of the Rayleigh quotient over span{x, w} — the 2 x 2 pencil of
+    MGCMTSolver.py:33-50 solved with scipy's eigh here — x + delta w, its gradient 2 (A x' - rho M x') (:52-54) and the
+    recorded Rayleigh quotient; with and without a mass operator, and the direction-free form (rho and g of x alone)."""
+    import scipy.linalg
+    import scipy.sparse as sp
+    from multigridcmt_amd import _lib
+    from multigridcmt_amd.operators import potential_well_operator, recognise
+    from multigridcmt_amd.plan import get_plan
+    g = 32
+    op = potential_well_operator(g, 30.0, (8, 24))
+    A = op.tocsr()
+    m1 = sp.diags([np.full(g - 1, 1 / 6), np.full(g, 2 / 3), np.full(g - 1, 1 / 6)], [-1, 0, 1])
+    M = sp.kron(m1, m1).tocsr() if with_mass else sp.eye(g * g, format="csr")
+    plan = get_plan(op, 8, nvec=3, mass=recognise(M, "2d") if with_mass else None)
+    rng = np.random.RandomState(5)
+    x, w = rng.rand(g * g), rng.rand(g * g) - 0.5
+    V, F, W = _lib.SLOT_V, _lib.SLOT_F, _lib.SLOT_W
+    X, PW, XO, G, WORK = (W, 1), (V, 0), (W, 0), (F, 0), (W, 2)
+    plan.upload(0, X[0], X[1], x)
+    plan.upload(0, PW[0], PW[1], w)
+    plan.rq_line_step(0, X, None, None, G, work=WORK if with_mass else None, record=0)
+    rho0 = x @ (A @ x) / (x @ (M @ x))
+    assert rel_err(plan.download(0, G[0], G[1]), 2 * (A @ x - rho0 * (M @ x))) < 1e-12
+    plan.rq_line_step(0, X, PW, XO, G, work=WORK if with_mass else None, record=1)
+    B = np.stack([x, w], axis=1)
+    evals, evecs = scipy.linalg.eigh(B.T @ (A @ B), B.T @ (M @ B))
+    y = evecs[:, 0]
+    xn = x + (y[1] / y[0]) * w
+    rho = xn @ (A @ xn) / (xn @ (M @ xn))
+    assert abs(rho - evals[0]) < 1e-12 * abs(rho)
+    assert rel_err(plan.download(0, XO[0], XO[1]), xn) < 1e-11
+    gn = 2 * (A @ xn - rho * (M @ xn))
+    assert np.linalg.norm(plan.download(0, G[0], G[1]) - gn) < 1e-10 * np.linalg.norm(2 * (A @ xn))
+    assert np.allclose(plan.rq_history(0, 2), [rho0, rho], rtol=1e-12, atol=0)
+    assert np.array_equal(plan.download(0, X[0], X[1]), x)            # x itself is only read
+    with pytest.raises(_lib.MgcmtError):
+        plan.rq_line_step(0, X, PW, X, G)                              # the vectors must be distinct
+    if with_mass:
+        with pytest.raises(_lib.MgcmtError):
+            plan.rq_line_step(0, X, PW, XO, G)                         # a mass operator needs the work vector
