@@ -5,7 +5,7 @@ import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = os.path.join(ROOT, "gpurun_out")
 out = {}
-for what, names in (("1d", ("k_fused1d",)), ("rqmg", ("k_rq_pass1<3, 0>", "k_rq_pass2<3, 0>", "k_rq_pass1<3, 1>", "k_rq_pass2<3, 1>", "k_rq_gmg"))):
+for what, names in (("1d", ("k_fused1d",)), ("rqmg", ("k_rq_pass1<6, 0>", "k_rq_pass2<6, 0>", "k_rq_pass1<3, 1>", "k_rq_pass2<3, 1>", "k_rq_gmg"))):
     per = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         files = glob.glob(os.path.join(g, "pmc_r03_%s_%s" % (what, counter), "**", "*counter_collection.csv"), recursive=True)
