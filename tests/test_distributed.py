@@ -92,6 +92,12 @@ def test_sharded_cycle_equals_single_plan(tmp_path, world, kind_name, force_reco
     assert abs(res - want_res) < 1e-9 * want_res
 
 
+def test_sharded_cycle_with_eight_ranks(tmp_path):
+    """The job size the round driver launches (N = 8): two end ranks, six interior ones, eight strips gathered for the
+    redundant coarse sub-cycle — 2048^2, strips of 256 rows down to 512^2, against the single plan."""
+    test_sharded_cycle_equals_single_plan(tmp_path, 8, "rb", False, 2048)
+
+
 @pytest.mark.parametrize("kind_name", ["wjacobi", "rb"])
 def test_sharded_square_well_equals_single_plan(tmp_path, kind_name):
     """The same on the square-well Hamiltonian (BASELINE config 5's operator): the strips of the finest level run the
