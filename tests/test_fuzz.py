@@ -107,22 +107,29 @@ def test_random_rayleigh_quotient_minimisations(backend):
             x, rho = solver.vcycle_rqmg(x0.copy(), A, M, nu1=nu, nu2=nu, nmin=nmin)
         else:
             x, rho = solver.rqmin(A, x0.copy(), M, nu=nu)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            try:
-                if use_cycle:
-                    xr, rr = ref.vcycle_rqmg(x0.copy(), A, M, nu1=nu, nu2=nu, nmin=nmin, dimension=dim)
-                else:
-                    xr, rr = ref.rqmin(A, x0.copy(), M, nu=nu)
-            except ValueError:                       # scipy's eig refusing the NaNs of a degenerate pencil (below)
-                xr, rr = np.full_like(x0, np.nan), np.nan
-        xr, rr = np.real(xr), float(np.real(rr))
         assert np.all(np.isfinite(x)) and np.isfinite(rho), case
-        if not (np.all(np.isfinite(xr)) and np.isfinite(rr)):
-            # the reference's arithmetic has no answer here: a gradient of exact zeros (x an eigenvector to the last bit, as on
-            # a 2-point level after one step) makes its 2 x 2 pencil singular and eig returns NaNs; the device code leaves x
-            # as it is — nothing to compare with, but the result must be a Rayleigh quotient of x
-            assert abs(rho - x @ (A @ x) / (x @ (M @ x))) < 1e-9 * abs(rho), case
-            continue
-        assert abs(rho - rr) < 1e-9 * abs(rr), (case, rho, rr)
-        assert rel_err(x, xr) < 1e-7, (case, rel_err(x, xr))
+        # two comparisons: tightly with the CPU restatement whose 2 x 2 pencils are solved in closed form (extended
+        # precision), loosely with the faithful one (LAPACK's QZ, as the reference): QZ's delta carries a forward error of up
+        # to ~1e-9 on the badly scaled pencils of a random start vector on a fine grid (oracle/sparse_ref.py: exact_pencil)
+        for exact, tol_rho, tol_x in ((True, 1e-10, 1e-8), (False, 1e-6, 1e-5)):
+            ref.exact_pencil = exact
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                try:
+                    if use_cycle:
+                        xr, rr = ref.vcycle_rqmg(x0.copy(), A, M, nu1=nu, nu2=nu, nmin=nmin, dimension=dim)
+                    else:
+                        xr, rr = ref.rqmin(A, x0.copy(), M, nu=nu)
+                except ValueError:                   # scipy's eig refusing the NaNs of a degenerate pencil (below)
+                    xr, rr = np.full_like(x0, np.nan), np.nan
+                finally:
+                    ref.exact_pencil = False
+            xr, rr = np.real(xr), float(np.real(rr))
+            if not (np.all(np.isfinite(xr)) and np.isfinite(rr)):
+                # the reference's arithmetic has no answer here: a gradient of exact zeros (x an eigenvector to the last bit, as
+                # on a 2-point level after one step) makes its 2 x 2 pencil singular and eig returns NaNs; the device code
+                # leaves x as it is — nothing to compare with, but the result must be a Rayleigh quotient of x
+                assert abs(rho - x @ (A @ x) / (x @ (M @ x))) < 1e-9 * abs(rho), case
+                continue
+            assert abs(rho - rr) < tol_rho * abs(rr), (case, exact, rho, rr)
+            assert rel_err(x, xr) < tol_x, (case, exact, rel_err(x, xr))
