@@ -94,8 +94,8 @@ def test_sharded_cycle_equals_single_plan(tmp_path, world, kind_name, force_reco
 
 def test_sharded_cycle_with_eight_ranks(tmp_path):
     """The job size the round driver launches (N = 8): two end ranks, six interior ones, eight strips gathered for the
-    redundant coarse sub-cycle — 2048^2, strips of 256 rows down to 512^2, against the single plan."""
-    test_sharded_cycle_equals_single_plan(tmp_path, 8, "rb", False, 2048)
+    redundant coarse sub-cycle — 1024^2, strips of 128 rows down to 256^2, against the single plan."""
+    test_sharded_cycle_equals_single_plan(tmp_path, 8, "rb", False, 1024)
 
 
 @pytest.mark.parametrize("kind_name", ["wjacobi", "rb"])
