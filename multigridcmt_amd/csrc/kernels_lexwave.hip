@@ -60,6 +60,9 @@ constexpr int kTerminalRows = 16;  // (spare rows behind a block's records: the 
 #ifndef MGCMT_LEX_REC
 #define MGCMT_LEX_REC 4  // rows ahead at which the left block's records are asked for (tuning)
 #endif
+#ifndef MGCMT_LEX_PROGRESS_TRIPS
+#define MGCMT_LEX_PROGRESS_TRIPS 3  // chained sweeps: trips between two publications of a block's progress (tuning)
+#endif
 #ifndef MGCMT_LEX_CHAIN_REC
 #define MGCMT_LEX_CHAIN_REC 4  // chained sweeps: rows ahead at which records are asked for (tuning)
 #endif
@@ -150,7 +153,7 @@ __global__ void __launch_bounds__(64) k_lex_wave(LexWaveArgs a) {
   // row i + kRec, old values of row i + kDepth + 1]; loads complete in order, so the wait of step i — for the record of row
   // i, issued kRec steps ago — lets only what was issued after it stay in flight.
   constexpr int kRec = CH ? MGCMT_LEX_CHAIN_REC : MGCMT_LEX_REC;  // (chained sweeps load v past the caches: the longer latency wants more steps between a load and the wait behind it)
-  constexpr int kProgressTrips = 3;                   // chained sweeps: trips (of kSlots rows) between two publications of a block's progress
+  constexpr int kProgressTrips = MGCMT_LEX_PROGRESS_TRIPS;  // chained sweeps: trips (of kSlots rows) between two publications of a block's progress
   constexpr int kWaitN = (kLoads - 1) + (kRec - 1) * kOps;
   static_assert(kWaitN <= 63, "vmcnt is a 6-bit counter");
   static_assert(kRec < kDepth, "the old values of rows i, i + 1 are older than the record of row i (row i + 1 is asked for kDepth steps ahead, behind that step's record)");
