@@ -358,6 +358,34 @@ __global__ void k_prolong(KGrid fine, KGrid coarse, KVec e, KVec vv, int accumul
   *dst = accumulate ? *dst + val : val;
 }
 
+// the same for 2-D levels of even size: a thread owns the 2 x 2 fine points of coarse point (I, J) — four coarse values
+// (rows I - 1, I; columns J - 1, J) in, two 16-byte accesses per fine row out; the arithmetic per point is k_prolong's
+// (one thread per point there: 8-byte accesses and four coarse loads each — 3.6 TB/s on an 8192^2 level; 1.2 GB per launch)
+__global__ void __launch_bounds__(256) k_prolong_quad(KGrid fine, KGrid coarse, KVec e, KVec vv, int accumulate) {
+  const long J = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long I = (long)blockIdx.y * blockDim.y + threadIdx.y;
+  const long cnc = coarse.nc;
+  if (I >= coarse.nr || J >= cnc) return;
+  const int q = blockIdx.z;
+  const double* r1 = e.p + q * e.stride + I * cnc;
+  const double* r0 = r1 - cnc;  // coarse row I-1: the halo row when I == 0
+  const double c11 = r1[J], c10 = J > 0 ? r1[J - 1] : 0.0;
+  const double c01 = r0[J], c00 = J > 0 ? r0[J - 1] : 0.0;
+  const double a1e = 0.5 * (c11 + c10), a1o = c11;  // row I at the even / odd fine column
+  const double a0e = 0.5 * (c01 + c00), a0o = c01;  // row I - 1
+  double2 top = make_double2(0.5 * (a0e + a1e), 0.5 * (a0o + a1o));  // fine row 2I
+  double2 bot = make_double2(a1e, a1o);                              // fine row 2I + 1
+  double* d0 = vv.p + q * vv.stride + (2 * I) * fine.nc + 2 * J;
+  double* d1 = d0 + fine.nc;
+  if (accumulate) {
+    const double2 t = *reinterpret_cast<const double2*>(d0), b = *reinterpret_cast<const double2*>(d1);
+    top = make_double2(t.x + top.x, t.y + top.y);
+    bot = make_double2(b.x + bot.x, b.y + bot.y);
+  }
+  *reinterpret_cast<double2*>(d0) = top;
+  *reinterpret_cast<double2*>(d1) = bot;
+}
+
 inline dim3 grid2d(long nc, long nr, int k, dim3 b) {
   return dim3((unsigned)((nc + b.x - 1) / b.x), (unsigned)((nr + b.y - 1) / b.y), (unsigned)k);
 }
@@ -432,6 +460,12 @@ void launch_restrict(hipStream_t s, KGrid fine, KGrid coarse, KVec r, KVec rc, i
 }
 
 void launch_prolong(hipStream_t s, KGrid fine, KGrid coarse, KVec e, KVec v, int accumulate, int k) {
+  const bool quads = fine.coarsen_rows && fine.nr == 2 * coarse.nr && fine.nc == 2 * coarse.nc && (((uintptr_t)v.p) & 15) == 0 && (v.stride & 1) == 0;
+  if (quads) {
+    const dim3 b(64, 4, 1);
+    hipLaunchKernelGGL(k_prolong_quad, grid2d(coarse.nc, coarse.nr, k, b), b, 0, s, fine, coarse, e, v, accumulate);
+    return;
+  }
   const dim3 b = block_for(fine.nr);
   hipLaunchKernelGGL(k_prolong, grid2d(fine.nc, fine.nr, k, b), b, 0, s, fine, coarse, e, v, accumulate);
 }
