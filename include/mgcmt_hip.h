@@ -339,6 +339,10 @@ typedef enum mgcmt_option {
                                0: one workgroup per vector everywhere */
   MGCMT_OPT_LEX_CHAIN = 6,  /* default 1: the nu Gauss-Seidel sweeps of a smoothing step run chained in ONE launch of the scan pipeline
                                (sweep s + 1 follows sweep s a few rows behind); 0: one launch per sweep.  Same arithmetic, same bits */
+  MGCMT_OPT_MGS_BLOCK = 7,  /* default 1: modified Gram-Schmidt of 2..12 long columns as two passes over the data (Gram matrix,
+                               its Cholesky factor R, Q = A R^-1 — what MGCMTProcessor.py:44-50 computes in exact arithmetic),
+                               with the column-by-column kernels taking over on the device where the columns' condition
+                               number would let the difference (cond^2 eps) show; 0: column by column always */
   MGCMT_OPT_TAIL = 4        /* default 1: the 2-D levels of at most 32 x 32 points below a cycle's top level, coarse solve
                                included, run as ONE launch (needs MGCMT_OPT_FUSED; not with Gram-Schmidt): a dense product
                                with the tail's matrix — the sub-cycle is linear in its right-hand side for fixed shift,

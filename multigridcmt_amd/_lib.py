@@ -26,6 +26,7 @@ OPT_FUSED_ROWS = 1
 OPT_TAIL = 4
 OPT_LEX_WAVE = 5
 OPT_LEX_CHAIN = 6
+OPT_MGS_BLOCK = 7
 OPT_GRAPH = 2
 OPT_RECOMPUTE = 3
 

@@ -55,7 +55,8 @@ __device__ __forceinline__ double block_sum(double v, double* s_buf) {
 
 // partials[q*gridDim.x + b] = sum over block b's slice of x[i]*y_q[i]
 __global__ void __launch_bounds__(kRedThreads) k_dot_partial(long n, const double* __restrict__ x, const double* __restrict__ y, long ystride,
-                                                             double* __restrict__ partials) {
+                                                             double* __restrict__ partials, const double* __restrict__ gate) {
+  if (gate && gate[0] == 0.0) return;  // (the first launch of the column-by-column Gram-Schmidt behind the blocked form)
   __shared__ double s_buf[kRedThreads / 64];
   const int q = blockIdx.y;
   const double* yq = y + q * ystride;
@@ -112,7 +113,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // VEC2: 16-byte accesses (n even, 16-byte aligned columns) — the pass is pure streaming
 template <bool VEC2>
 __global__ void __launch_bounds__(kRedThreads) k_mgs_step(long n, const double* __restrict__ pin, int nb_in, double* __restrict__ u, long stride,
-                                                          int m, double* __restrict__ pout) {
+                                                          int m, double* __restrict__ pout, const double* __restrict__ gate) {
+  if (gate && gate[0] == 0.0) return;  // the blocked form has done the columns (launch_mgs_blocked)
   constexpr int kWaves = kRedThreads / 64;
   __shared__ double s_sum[kMaxVec + 1];
   __shared__ double s_part[kWaves][kMaxVec];
@@ -186,6 +188,161 @@ __global__ void __launch_bounds__(kRedThreads) k_mgs_step(long n, const double* 
     double tot = 0.0;
     for (int w = 0; w < kWaves; ++w) tot += s_part[w][threadIdx.x];
     pout[(long)threadIdx.x * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
+// ---- modified Gram-Schmidt of k long columns in TWO passes over the data ----------------------------------------------
+// Column by column (k_mgs_step) the orthonormalisation of k columns moves k^2 + k vector streams — 110 for k = 10, 58 % of a
+// 4096^2 vcycle_matrix cycle.  In exact arithmetic its result is the Q of A = Q R with a positive diagonal of R
+// (MGCMTProcessor.py:44-50), and R^T R = A^T A: one pass forms the Gram matrix (k streams), one workgroup factors it —
+// after scaling it to unit diagonal, so that the columns' lengths do not enter — and inverts R, one pass forms
+// Q = A R^-1 in place (2 k streams).  The two differ by rounding errors of the order cond(A)^2 eps, so the factoring
+// workgroup also bounds the condition number (||R||_F ||R^-1||_F of the scaled factor) and, beyond kMgsBlockCond — or on a
+// pivot that is not positive, or anything not finite — sets a gate word that sends the columns through the
+// column-by-column kernels instead (they are launched behind this form in any case and return at once when the gate
+// is down: a launch sequence without a host round trip, fit for graph capture).  The iterates of the eigen-solver loops are
+// nearly orthonormal from the cycle before (cond ~ 1 - 3: differences of 1e-15); the epsilon vectors of
+// UnitTests/GramSchmidt.py (cond 1e8) are what the gate is for.
+constexpr int kMgsBlockMax = 12;
+constexpr int kMgsPairsMax = kMgsBlockMax * (kMgsBlockMax + 1) / 2;
+constexpr int kMgsGramBlocks = 768;         // kMgsPairsMax * kMgsGramBlocks doubles of partial sums
+constexpr double kMgsBlockCond = 100.0;     // ||R||_F ||R^-1||_F of the unit-diagonal Gram matrix's factor (k for orthonormal columns)
+constexpr int kMgsGateWord = kMgsBlockMax * kMgsBlockMax;  // out[kMgsGateWord]: 0 = done here, 1 = column by column
+
+__global__ void __launch_bounds__(kRedThreads) k_mgs_gram(long n, const double* __restrict__ a0, long stride, int k, double* __restrict__ partials) {
+  constexpr int kWaves = kRedThreads / 64;
+  __shared__ double s_part[kWaves][kMgsPairsMax];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc[kMgsPairsMax];
+#pragma unroll
+  for (int t = 0; t < kMgsPairsMax; ++t) acc[t] = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double x[kMgsBlockMax];
+#pragma unroll
+    for (int a = 0; a < kMgsBlockMax; ++a) x[a] = a < k ? a0[a * stride + i] : 0.0;
+#pragma unroll
+    for (int a = 0; a < kMgsBlockMax; ++a) {
+      if (a < k) {  // (wave-uniform)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) acc[a * (a + 1) / 2 + b] = fma(x[a], x[b], acc[a * (a + 1) / 2 + b]);
+      }
+    }
+  }
+  const int npairs = k * (k + 1) / 2;
+#pragma unroll
+  for (int t = 0; t < kMgsPairsMax; ++t) {
+    if (t < npairs) {  // (wave-uniform)
+      const double tot = wave_sum(acc[t]);
+      if (lane == 0) s_part[wave][t] = tot;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < npairs) {
+    double tot = 0.0;
+    for (int w = 0; w < kWaves; ++w) tot += s_part[w][threadIdx.x];
+    partials[(long)threadIdx.x * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
+// out[i * kMgsBlockMax + j] = (R^-1)[i][j] (i <= j), out[kMgsGateWord] = the gate
+__global__ void __launch_bounds__(kRedThreads) k_mgs_factor(const double* __restrict__ partials, int nblocks, int k, double* __restrict__ out) {
+  __shared__ double G[kMgsPairsMax];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npairs = k * (k + 1) / 2;
+  for (int t0 = 0; t0 < npairs; t0 += kRedThreads / 64) {  // one wave per sum: lane-strided, then the shuffle tree
+    const int t = t0 + wave;
+    double acc = 0.0;
+    if (t < npairs)
+      for (int i = lane; i < nblocks; i += 64) acc += partials[(long)t * nblocks + i];
+    const double tot = wave_sum(acc);
+    if (lane == 0 && t < npairs) G[t] = tot;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  auto g = [&](int a, int b) { return a >= b ? G[a * (a + 1) / 2 + b] : G[b * (b + 1) / 2 + a]; };
+  double d[kMgsBlockMax], R[kMgsBlockMax][kMgsBlockMax], C[kMgsBlockMax][kMgsBlockMax];
+  bool ok = true;
+  for (int i = 0; i < k; ++i) {
+    const double gi = g(i, i);
+    if (!(gi > 0.0) || !(gi <= 1.7e308)) ok = false;
+    d[i] = ok ? 1.0 / sqrt(gi) : 0.0;
+  }
+  for (int i = 0; i < kMgsBlockMax; ++i)
+    for (int j = 0; j < kMgsBlockMax; ++j) R[i][j] = C[i][j] = 0.0;
+  // Cholesky of the unit-diagonal matrix d G d = R^T R, R upper triangular
+  for (int j = 0; j < k && ok; ++j) {
+    for (int i = 0; i <= j; ++i) {
+      double sum = g(j, i) * d[i] * d[j];
+      for (int t = 0; t < i; ++t) sum -= R[t][i] * R[t][j];
+      if (i == j) {
+        if (!(sum > 0.0)) ok = false;
+        else R[j][j] = sqrt(sum);
+      } else {
+        R[i][j] = sum / R[i][i];
+      }
+    }
+  }
+  double fr = 0.0, fc = 0.0;
+  if (ok) {
+    for (int j = 0; j < k; ++j) {  // C = R^-1, column by column
+      C[j][j] = 1.0 / R[j][j];
+      for (int i = j - 1; i >= 0; --i) {
+        double sum = 0.0;
+        for (int t = i + 1; t <= j; ++t) sum += R[i][t] * C[t][j];
+        C[i][j] = -sum / R[i][i];
+      }
+    }
+    for (int i = 0; i < k; ++i)
+      for (int j = i; j < k; ++j) {
+        fr += R[i][j] * R[i][j];
+        fc += C[i][j] * C[i][j];
+      }
+    if (!(fr * fc <= kMgsBlockCond * kMgsBlockCond)) ok = false;  // (false for NaNs too)
+  }
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) out[i * kMgsBlockMax + j] = ok ? d[i] * C[i][j] : 0.0;  // A (d C) = Q
+  out[kMgsGateWord] = ok ? 0.0 : 1.0;
+}
+
+// Q = A C in place (C upper triangular): a thread reads the k values of its point (VEC2: of two points) before it writes any
+template <bool VEC2>
+__global__ void __launch_bounds__(256) k_mgs_apply(long n, double* __restrict__ a0, long stride, int k, const double* __restrict__ cf) {
+  if (cf[kMgsGateWord] != 0.0) return;
+  __shared__ double C[kMgsBlockMax * kMgsBlockMax];
+  for (int t = threadIdx.x; t < kMgsBlockMax * kMgsBlockMax; t += blockDim.x) C[t] = cf[t];
+  __syncthreads();
+  const long count = VEC2 ? n / 2 : n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    if (VEC2) {
+      double2 x[kMgsBlockMax];
+#pragma unroll
+      for (int a = 0; a < kMgsBlockMax; ++a) x[a] = a < k ? reinterpret_cast<const double2*>(a0 + a * stride)[i] : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int j = 0; j < kMgsBlockMax; ++j) {
+        if (j < k) {
+          double2 q = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int a = 0; a <= j; ++a) {
+            q.x = fma(C[a * kMgsBlockMax + j], x[a].x, q.x);
+            q.y = fma(C[a * kMgsBlockMax + j], x[a].y, q.y);
+          }
+          reinterpret_cast<double2*>(a0 + j * stride)[i] = q;
+        }
+      }
+    } else {
+      double x[kMgsBlockMax];
+#pragma unroll
+      for (int a = 0; a < kMgsBlockMax; ++a) x[a] = a < k ? a0[a * stride + i] : 0.0;
+#pragma unroll
+      for (int j = 0; j < kMgsBlockMax; ++j) {
+        if (j < k) {
+          double q = 0.0;
+#pragma unroll
+          for (int a = 0; a <= j; ++a) q = fma(C[a * kMgsBlockMax + j], x[a], q);
+          a0[j * stride + i] = q;
+        }
+      }
+    }
   }
 }
 
@@ -532,8 +689,8 @@ void launch_final_sums(hipStream_t s, int nq, int nblocks, const double* partial
 }
 
 // first pass only: partials[q*reduce_blocks(n) + b]
-void launch_dot_partials(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials) {
-  hipLaunchKernelGGL(k_dot_partial, dim3(reduce_blocks(n), nq), dim3(kRedThreads), 0, s, n, x, y, ystride, partials);
+void launch_dot_partials(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, const double* gate) {
+  hipLaunchKernelGGL(k_dot_partial, dim3(reduce_blocks(n), nq), dim3(kRedThreads), 0, s, n, x, y, ystride, partials, gate);
 }
 
 void launch_scale_by_norm(hipStream_t s, long n, const double* partials, double* x) {
@@ -596,17 +753,34 @@ void launch_mgs_small(hipStream_t s, long n, double* a0, long stride, int k) {
   hipLaunchKernelGGL(k_mgs_small, dim3(1), dim3(kMgsSmallThreads), 0, s, n, a0, stride, k);
 }
 
-void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out, int nb_in) {
+int mgs_block_max() { return kMgsBlockMax; }
+int mgs_block_words() { return kMgsGateWord + 1; }
+int mgs_block_gate_word() { return kMgsGateWord; }
+
+// the blocked form (k_mgs_gram, k_mgs_factor, k_mgs_apply) on the k columns a0, a0 + stride, ...; partials: at least
+// 78 * 768 doubles; cf: mgs_block_words() doubles whose gate word the column-by-column launches behind this take
+void launch_mgs_blocked(hipStream_t s, long n, double* a0, long stride, int k, double* partials, double* cf) {
+  long blocks = (n + kRedThreads - 1) / kRedThreads;
+  if (blocks > kMgsGramBlocks) blocks = kMgsGramBlocks;
+  hipLaunchKernelGGL(k_mgs_gram, dim3((unsigned)blocks), dim3(kRedThreads), 0, s, n, a0, stride, k, partials);
+  hipLaunchKernelGGL(k_mgs_factor, dim3(1), dim3(kRedThreads), 0, s, partials, (int)blocks, k, cf);
+  const bool vec2 = (n & 1) == 0 && (stride & 1) == 0 && (((uintptr_t)a0) & 15) == 0;
+  if (vec2) hipLaunchKernelGGL((k_mgs_apply<true>), dim3(blocks_for(n / 2)), dim3(256), 0, s, n, a0, stride, k, cf);
+  else hipLaunchKernelGGL((k_mgs_apply<false>), dim3(blocks_for(n)), dim3(256), 0, s, n, a0, stride, k, cf);
+}
+
+void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out, int nb_in,
+                     const double* gate) {
   const int nb = reduce_blocks(n);
   if (nb_in <= 0) nb_in = nb;
   const bool vec2 = (n & 1) == 0 && (stride & 1) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0;
-  if (vec2) hipLaunchKernelGGL(k_mgs_step<true>, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb_in, u, stride, m, partials_out);
-  else hipLaunchKernelGGL(k_mgs_step<false>, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb_in, u, stride, m, partials_out);
+  if (vec2) hipLaunchKernelGGL(k_mgs_step<true>, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb_in, u, stride, m, partials_out, gate);
+  else hipLaunchKernelGGL(k_mgs_step<false>, dim3(nb), dim3(kRedThreads), 0, s, n, partials_in, nb_in, u, stride, m, partials_out, gate);
 }
 
 void launch_dots(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, double* out) {
   const int nb = reduce_blocks(n);
-  hipLaunchKernelGGL(k_dot_partial, dim3(nb, nq), dim3(kRedThreads), 0, s, n, x, y, ystride, partials);
+  hipLaunchKernelGGL(k_dot_partial, dim3(nb, nq), dim3(kRedThreads), 0, s, n, x, y, ystride, partials, (const double*)nullptr);
   hipLaunchKernelGGL(k_dot_final, dim3(nq), dim3(kRedThreads), 0, s, nb, partials, out);
 }
 

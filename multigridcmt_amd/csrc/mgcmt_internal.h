@@ -128,7 +128,7 @@ int reduce_blocks(long n);
 void launch_dots(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, double* out);
 // Gram-Schmidt building blocks that consume the first reduction pass directly (no separate final pass / no scalar
 // round trip): x /= sqrt(sum partials);  a_j -= (<q,a_j>/<q,q>) q for nj columns in one launch
-void launch_dot_partials(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials);
+void launch_dot_partials(hipStream_t s, long n, const double* x, const double* y, long ystride, int nq, double* partials, const double* gate = nullptr);
 void launch_scale_by_norm(hipStream_t s, long n, const double* partials, double* x);
 void launch_project_out(hipStream_t s, long n, const double* partials, const double* q, double* a_first, long astride, int nj);
 constexpr int kGramMaxVectors = 6;
@@ -184,7 +184,14 @@ void launch_tail_matrix(hipStream_t s, TailArgs a, int q, double* mt);
 void launch_tail_dense(hipStream_t s, long g0, const double* mt, long mt_stride, const double* f_in, double* v_out, long vstride, int k);
 void launch_mgs_small(hipStream_t s, long n, double* a0, long stride, int k);
 // nb_in: partial sums per result in partials_in (0 = reduce_blocks(n), what the previous step left; 1 = already summed)
-void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out, int nb_in = 0);
+void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out, int nb_in = 0,
+                     const double* gate = nullptr);
+// modified Gram-Schmidt of up to mgs_block_max() long columns in two passes over the data (Gram matrix, its factor, Q = A R^-1),
+// with a gate word (cf[mgs_block_gate_word()]: 0 = done) for the column-by-column launches behind it: kernels_blas.hip
+int mgs_block_max();
+int mgs_block_words();
+int mgs_block_gate_word();
+void launch_mgs_blocked(hipStream_t s, long n, double* a0, long stride, int k, double* partials, double* cf);
 
 // banded LU of (A - mu I) on the coarsest level and its solves (one workgroup per vector)
 struct KBand {

@@ -598,11 +598,19 @@ int gramschmidt_impl(mgcmt_plan* p, int l, int slot, int k, int modified, hipStr
       launch_mgs_small(s, n, a0, stride, k);  // short columns: everything in one workgroup
       return post_launch();
     }
+    // Long columns: first the blocked form — Gram matrix, its factor, Q = A R^-1: 3 k vector streams instead of k^2 + k —
+    // which leaves a gate word up where its rounding errors (cond^2 eps) would show; the column-by-column launches
+    // behind it return at once when the gate is down (MGCMT_OPT_MGS_BLOCK = 0: column by column only)
+    const double* gate = nullptr;
+    if (p->use_mgs_block && k >= 2 && k <= mgs_block_max()) {
+      launch_mgs_blocked(s, n, a0, stride, k, p->d_partials, p->d_mgs);
+      gate = p->d_mgs + mgs_block_gate_word();
+    }
     double* pa = p->d_partials;
     double* pb = p->d_partials + (long)(kMaxVec + 1) * 1024;
-    launch_dot_partials(s, n, a0, a0, stride, k, pa);  // <a_0, a_t>, t = 0..k-1
+    launch_dot_partials(s, n, a0, a0, stride, k, pa, gate);  // <a_0, a_t>, t = 0..k-1
     for (int i = 0; i < k; ++i) {
-      launch_mgs_step(s, n, pa, a0 + i * stride, stride, k - 1 - i, pb);
+      launch_mgs_step(s, n, pa, a0 + i * stride, stride, k - 1 - i, pb, 0, gate);
       std::swap(pa, pb);
     }
     (void)sc;
@@ -890,6 +898,7 @@ int mgcmt_plan_create(const mgcmt_plan_desc* d, mgcmt_plan** out) {
   hipError_t e = hipMalloc((void**)&p->d_shifts, sizeof(double) * kMaxVec);
   if (e == hipSuccess) e = hipMalloc((void**)&p->d_zero, sizeof(double) * kMaxVec);
   if (e == hipSuccess) e = hipMalloc((void**)&p->d_partials, sizeof(double) * (kMaxVec + 1) * 1024 * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_mgs, sizeof(double) * mgs_block_words());
   if (e == hipSuccess) e = hipMalloc((void**)&p->d_scalars, sizeof(double) * 4 * kMaxVec);
   if (e == hipSuccess) e = hipMemset(p->d_shifts, 0, sizeof(double) * kMaxVec);
   if (e == hipSuccess) e = hipMemset(p->d_zero, 0, sizeof(double) * kMaxVec);
@@ -919,6 +928,7 @@ int mgcmt_plan_destroy(mgcmt_plan* p) {
   if (p->d_rq) (void)hipFree(p->d_rq);
   if (p->d_rqstate) (void)hipFree(p->d_rqstate);
   if (p->d_rqhistory) (void)hipFree(p->d_rqhistory);
+  if (p->d_mgs) (void)hipFree(p->d_mgs);
   if (p->tailmat.mt) (void)hipFree(p->tailmat.mt);
   if (p->lex_carry) (void)hipFree(p->lex_carry);
   if (p->lex_sync) (void)hipFree(p->lex_sync);
@@ -1686,6 +1696,11 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
   if (option == MGCMT_OPT_TAIL) {
     p->use_tail = value != 0;
     p->use_tail_dense = value != 2;  // 1 (default): the tail as one dense product; 2: as the LDS-resident launch of ~45 phases
+    p->graphs_invalidate();
+    return MGCMT_OK;
+  }
+  if (option == MGCMT_OPT_MGS_BLOCK) {
+    p->use_mgs_block = value != 0;
     p->graphs_invalidate();
     return MGCMT_OK;
   }

@@ -70,6 +70,8 @@ struct mgcmt_plan {
   double* d_scalars = nullptr;  // [4*kMaxVec] reduction results
   double* d_rq = nullptr;       // Gram results of mgcmt_rayleigh_residual, one block per column
   double* d_rqstate = nullptr;  // scalars of the device-resident Rayleigh-quotient minimisation (kernels_rq.hip)
+  double* d_mgs = nullptr;  // the blocked Gram-Schmidt's R^-1 and gate word (kernels_blas.hip)
+  bool use_mgs_block = true;
   double* d_rqhistory = nullptr;  // Rayleigh quotients recorded by mgcmt_rq_line_step (MGCMT_RQ_HISTORY numbers)
   std::vector<double> h_shifts;
   bool has_mass = false;

@@ -456,3 +456,42 @@ def test_cycle_tail_in_one_launch(backend, kind, omega):
             p.close()
         assert rel_err(outs[0], outs[2]) < 1e-12, (op.g, lowest, k, "dense")
         assert rel_err(outs[1], outs[2]) < 1e-12, (op.g, lowest, k, "phases")
+
+
+@pytest.mark.parametrize("k", [2, 6, 10, 12])
+def test_blocked_gram_schmidt_of_long_columns(backend, k):
+    """MGCMT_OPT_MGS_BLOCK: the modified Gram-Schmidt of MGCMTProcessor.py:44-50 on columns too long for one workgroup as two
+    passes over the data (Gram matrix, its Cholesky factor R, Q = A R^-1 — the same Q in exact arithmetic).  Well-conditioned
+    columns (multigrid iterates are nearly orthonormal from the cycle before): equal to the column-by-column kernels and to
+    the CPU restatement to rounding, orthonormal to rounding, column lengths of any size.  Ill-conditioned columns (the epsilon
+    vectors of UnitTests/GramSchmidt.py stretched to long columns, cond 1e8): the gate on the device sends them through the
+    column-by-column kernels — bit for bit what the option switched off computes."""
+    from oracle.sparse_ref import RefProcessor
+    from multigridcmt_amd.operators import laplacian_operator
+    g = 128                                            # 16384 points: more than one workgroup's worth
+    n = g * g
+    rng = np.random.RandomState(3 + k)
+    Q0 = np.linalg.qr(rng.rand(n, k))[0]
+    mix = np.eye(k) + 0.2 * rng.rand(k, k)             # cond ~ 2-4
+    A = (Q0 @ mix) * (10.0 ** rng.randint(-3, 4, size=k))[None, :]      # columns of very different lengths
+    eps = 1e-8
+    L = np.zeros((n, k))
+    L[0, :] = 1.0
+    for j in range(k):
+        L[1 + j::k + 1, j] = eps                       # Laeuchli-type: pairwise nearly parallel
+    p = Plan(laplacian_operator(g, "2d"), 8, nvec=k)
+    results = {}
+    for name, cols in (("well", A), ("ill", L)):
+        for opt in (1, 0):
+            p.set_option(_lib.OPT_MGS_BLOCK, opt)
+            for q in range(k):
+                p.upload(0, _lib.SLOT_V, q, cols[:, q])
+            p.gramschmidt(0, _lib.SLOT_V, k, modified=1)
+            results[(name, opt)] = np.stack([p.download(0, _lib.SLOT_V, q) for q in range(k)], axis=1)
+    p.close()
+    want = RefProcessor().gramschmidt(A, modified=1)
+    assert np.abs(results[("well", 1)] - results[("well", 0)]).max() < 5e-14
+    assert np.abs(results[("well", 1)] - want).max() < 5e-14
+    assert np.abs(results[("well", 1)].T @ results[("well", 1)] - np.eye(k)).max() < 1e-13
+    assert np.array_equal(results[("ill", 1)], results[("ill", 0)])
+    assert np.abs(results[("ill", 0)] - RefProcessor().gramschmidt(L, modified=1)).max() < 1e-6    # (cond 1e8: summation orders show at cond * eps)
