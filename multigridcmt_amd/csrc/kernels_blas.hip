@@ -208,6 +208,7 @@ constexpr int kMgsPairsMax = kMgsBlockMax * (kMgsBlockMax + 1) / 2;
 constexpr int kMgsGramBlocks = 768;         // kMgsPairsMax * kMgsGramBlocks doubles of partial sums
 constexpr double kMgsBlockCond = 100.0;     // ||R||_F ||R^-1||_F of the unit-diagonal Gram matrix's factor (k for orthonormal columns)
 constexpr int kMgsGateWord = kMgsBlockMax * kMgsBlockMax;  // out[kMgsGateWord]: 0 = done here, 1 = column by column
+constexpr int kMgsFactorThreads = 1024;
 
 __global__ void __launch_bounds__(kRedThreads) k_mgs_gram(long n, const double* __restrict__ a0, long stride, int k, double* __restrict__ partials) {
   constexpr int kWaves = kRedThreads / 64;
@@ -244,64 +245,96 @@ __global__ void __launch_bounds__(kRedThreads) k_mgs_gram(long n, const double* 
   }
 }
 
-// out[i * kMgsBlockMax + j] = (R^-1)[i][j] (i <= j), out[kMgsGateWord] = the gate
-__global__ void __launch_bounds__(kRedThreads) k_mgs_factor(const double* __restrict__ partials, int nblocks, int k, double* __restrict__ out) {
+// out[i * kMgsBlockMax + j] = (R^-1)[i][j] (i <= j), out[kMgsGateWord] = the gate.  One workgroup; the factorisation runs on
+// a thread per matrix entry (LDS, two barriers per pivot), the inverse on a thread per column: a few microseconds (a
+// first form — thread 0 alone with its arrays in scratch memory — took 147 us per launch)
+__global__ void __launch_bounds__(kMgsFactorThreads) k_mgs_factor(const double* __restrict__ partials, int nblocks, int k, double* __restrict__ out) {
+  constexpr int K = kMgsBlockMax;
   __shared__ double G[kMgsPairsMax];
+  __shared__ double W[K][K];  // the scaled Gram matrix, overwritten by R (upper triangle)
+  __shared__ double C[K][K];
+  __shared__ double d[K];
+  __shared__ double s_fr[K], s_fc[K];
+  __shared__ int s_bad;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int npairs = k * (k + 1) / 2;
-  for (int t0 = 0; t0 < npairs; t0 += kRedThreads / 64) {  // one wave per sum: lane-strided, then the shuffle tree
+  if (threadIdx.x == 0) s_bad = 0;
+  // one wave per sum (16 waves take the sums in turn): a lane issues all its loads — kMgsGramBlocks / 64 at most — before it adds
+  // the first (one memory latency per turn instead of one per load), then the shuffle tree
+  for (int t0 = 0; t0 < npairs; t0 += kMgsFactorThreads / 64) {
     const int t = t0 + wave;
+    double v[kMgsGramBlocks / 64];
+#pragma unroll
+    for (int u = 0; u < kMgsGramBlocks / 64; ++u) {
+      const int i = lane + 64 * u;
+      v[u] = (t < npairs && i < nblocks) ? partials[(long)t * nblocks + i] : 0.0;
+    }
     double acc = 0.0;
-    if (t < npairs)
-      for (int i = lane; i < nblocks; i += 64) acc += partials[(long)t * nblocks + i];
+#pragma unroll
+    for (int u = 0; u < kMgsGramBlocks / 64; ++u) acc += v[u];
     const double tot = wave_sum(acc);
     if (lane == 0 && t < npairs) G[t] = tot;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  auto g = [&](int a, int b) { return a >= b ? G[a * (a + 1) / 2 + b] : G[b * (b + 1) / 2 + a]; };
-  double d[kMgsBlockMax], R[kMgsBlockMax][kMgsBlockMax], C[kMgsBlockMax][kMgsBlockMax];
-  bool ok = true;
-  for (int i = 0; i < k; ++i) {
-    const double gi = g(i, i);
-    if (!(gi > 0.0) || !(gi <= 1.7e308)) ok = false;
-    d[i] = ok ? 1.0 / sqrt(gi) : 0.0;
+  const int ti = threadIdx.x / K, tj = threadIdx.x % K;  // this thread's entry (threads >= K * K idle along)
+  const bool entry = ti < k && tj < k && threadIdx.x < K * K;
+  if (threadIdx.x < k) {
+    const double gi = G[threadIdx.x * (threadIdx.x + 1) / 2 + threadIdx.x];
+    const bool fine = gi > 0.0 && gi <= 1.7e308;
+    if (!fine) s_bad = 1;
+    d[threadIdx.x] = fine ? 1.0 / sqrt(gi) : 0.0;
   }
-  for (int i = 0; i < kMgsBlockMax; ++i)
-    for (int j = 0; j < kMgsBlockMax; ++j) R[i][j] = C[i][j] = 0.0;
-  // Cholesky of the unit-diagonal matrix d G d = R^T R, R upper triangular
-  for (int j = 0; j < k && ok; ++j) {
+  __syncthreads();
+  if (entry) {
+    const int a = ti >= tj ? ti : tj, b = ti >= tj ? tj : ti;
+    W[ti][tj] = G[a * (a + 1) / 2 + b] * d[ti] * d[tj];
+    C[ti][tj] = 0.0;
+  }
+  __syncthreads();
+  // right-looking Cholesky W = R^T R: pivot t scales its row, every entry behind it takes the rank-one update
+  for (int t = 0; t < k; ++t) {
+    const double piv = W[t][t];
+    if (!(piv > 0.0)) {  // (every thread reads the same value: uniform)
+      if (threadIdx.x == 0) s_bad = 1;
+      break;
+    }
+    const double r = sqrt(piv);
+    __syncthreads();
+    if (entry && ti == t && tj >= t) W[t][tj] = tj == t ? r : W[t][tj] / r;
+    __syncthreads();
+    if (entry && ti > t && tj >= ti) W[ti][tj] -= W[t][ti] * W[t][tj];
+    __syncthreads();
+  }
+  __syncthreads();
+  const bool bad_factor = s_bad != 0;
+  if (!bad_factor && (int)threadIdx.x < k) {  // column j of C = R^-1 by back substitution, and the columns' share of the norms
+    const int j = threadIdx.x;
+    C[j][j] = 1.0 / W[j][j];
+    for (int i = j - 1; i >= 0; --i) {
+      double sum = 0.0;
+      for (int t = i + 1; t <= j; ++t) sum += W[i][t] * C[t][j];
+      C[i][j] = -sum / W[i][i];
+    }
+    double fr = 0.0, fc = 0.0;
     for (int i = 0; i <= j; ++i) {
-      double sum = g(j, i) * d[i] * d[j];
-      for (int t = 0; t < i; ++t) sum -= R[t][i] * R[t][j];
-      if (i == j) {
-        if (!(sum > 0.0)) ok = false;
-        else R[j][j] = sqrt(sum);
-      } else {
-        R[i][j] = sum / R[i][i];
-      }
+      fr += W[i][j] * W[i][j];
+      fc += C[i][j] * C[i][j];
     }
+    s_fr[j] = fr;
+    s_fc[j] = fc;
   }
-  double fr = 0.0, fc = 0.0;
+  __syncthreads();
+  bool ok = !bad_factor;
   if (ok) {
-    for (int j = 0; j < k; ++j) {  // C = R^-1, column by column
-      C[j][j] = 1.0 / R[j][j];
-      for (int i = j - 1; i >= 0; --i) {
-        double sum = 0.0;
-        for (int t = i + 1; t <= j; ++t) sum += R[i][t] * C[t][j];
-        C[i][j] = -sum / R[i][i];
-      }
+    double fr = 0.0, fc = 0.0;
+    for (int j = 0; j < k; ++j) {
+      fr += s_fr[j];
+      fc += s_fc[j];
     }
-    for (int i = 0; i < k; ++i)
-      for (int j = i; j < k; ++j) {
-        fr += R[i][j] * R[i][j];
-        fc += C[i][j] * C[i][j];
-      }
     if (!(fr * fc <= kMgsBlockCond * kMgsBlockCond)) ok = false;  // (false for NaNs too)
   }
-  for (int i = 0; i < k; ++i)
-    for (int j = 0; j < k; ++j) out[i * kMgsBlockMax + j] = ok ? d[i] * C[i][j] : 0.0;  // A (d C) = Q
-  out[kMgsGateWord] = ok ? 0.0 : 1.0;
+  if (entry) out[ti * K + tj] = ok && ti <= tj ? d[ti] * C[ti][tj] : 0.0;  // A (d C) = Q
+  if (threadIdx.x == 0) out[kMgsGateWord] = ok ? 0.0 : 1.0;
 }
 
 // Q = A C in place (C upper triangular): a thread reads the k values of its point (VEC2: of two points) before it writes any
@@ -763,7 +796,7 @@ void launch_mgs_blocked(hipStream_t s, long n, double* a0, long stride, int k, d
   long blocks = (n + kRedThreads - 1) / kRedThreads;
   if (blocks > kMgsGramBlocks) blocks = kMgsGramBlocks;
   hipLaunchKernelGGL(k_mgs_gram, dim3((unsigned)blocks), dim3(kRedThreads), 0, s, n, a0, stride, k, partials);
-  hipLaunchKernelGGL(k_mgs_factor, dim3(1), dim3(kRedThreads), 0, s, partials, (int)blocks, k, cf);
+  hipLaunchKernelGGL(k_mgs_factor, dim3(1), dim3(kMgsFactorThreads), 0, s, partials, (int)blocks, k, cf);
   const bool vec2 = (n & 1) == 0 && (stride & 1) == 0 && (((uintptr_t)a0) & 15) == 0;
   if (vec2) hipLaunchKernelGGL((k_mgs_apply<true>), dim3(blocks_for(n / 2)), dim3(256), 0, s, n, a0, stride, k, cf);
   else hipLaunchKernelGGL((k_mgs_apply<false>), dim3(blocks_for(n)), dim3(256), 0, s, n, a0, stride, k, cf);
