@@ -491,3 +491,27 @@ def test_rqmin_single_launch_equals_the_passes(trio, case, monkeypatch):
     (x1, rho1), (x0_, rho0) = out["1"], out["0"]
     assert abs(rho1 - rho0) < 1e-12 * abs(rho0)
     assert rel_err(x1, x0_) < 1e-10
+
+
+def test_vcycle_matrix_on_levels_with_long_columns(trio):
+    """vcycle_matrix (MGCMTSolver.py:375-436) at a size whose upper levels orthonormalise their columns by the two-pass
+    form of the modified Gram-Schmidt (csrc/kernels_blas.hip: Gram matrix, Cholesky factor, Q = A R^-1 — columns of more
+    than 4096 points) against the CPU restatement, which orthonormalises column by column as MGCMTProcessor.py:44-50
+    does: three outer iterations of the drivers' shift-and-invert loop (2DPotMatrixVcycle.py:91-105), 128^2, six columns."""
+    from oracle.sparse_ref import RefSolver
+    from multigridcmt_amd import _lib
+    solver, sm, _ = trio
+    g, k = 128, 6
+    A = H(sm, g, "2d")
+    modes = [(1, 1), (1, 2), (2, 1), (2, 2), (1, 3), (3, 1)]
+    shifts = np.array([0.98 * (a * a + b * b) for a, b in modes])          # just below the eigenvalues a^2 + b^2
+    rng = np.random.RandomState(4)
+    V = rng.rand(g * g, k)
+    Vr = V.copy()
+    ref = RefSolver()
+    for it in range(3):
+        w = solver.vcycle_matrix(np.zeros(V.shape), V, A, sm, shifts=shifts, lowest_level=8, dimension="2d")
+        wr = ref.vcycle_matrix(np.zeros(Vr.shape), Vr, A, sm, shifts=shifts, lowest_level=8, dimension="2d")
+        assert rel_err(w, wr) < NORTH_STAR, it
+        assert np.abs(w.T @ w - np.eye(k)).max() < 1e-12
+        V, Vr = w, wr
