@@ -790,16 +790,29 @@ int mgs_block_max() { return kMgsBlockMax; }
 int mgs_block_words() { return kMgsGateWord + 1; }
 int mgs_block_gate_word() { return kMgsGateWord; }
 
-// the blocked form (k_mgs_gram, k_mgs_factor, k_mgs_apply) on the k columns a0, a0 + stride, ...; partials: at least
-// 78 * 768 doubles; cf: mgs_block_words() doubles whose gate word the column-by-column launches behind this take
-void launch_mgs_blocked(hipStream_t s, long n, double* a0, long stride, int k, double* partials, double* cf) {
+// the blocked form's three launches: per-block partial sums of the Gram matrix's lower triangle (packed a (a + 1) / 2 + b;
+// returns the number of blocks: partials[pair * blocks + block], at most 78 * 768 doubles); the factor from sums of
+// `nblocks` partials each (1: the sums themselves — all-reduced over the ranks of a sharded plan); Q = A R^-1
+int launch_mgs_gram(hipStream_t s, long n, const double* a0, long stride, int k, double* partials) {
   long blocks = (n + kRedThreads - 1) / kRedThreads;
   if (blocks > kMgsGramBlocks) blocks = kMgsGramBlocks;
   hipLaunchKernelGGL(k_mgs_gram, dim3((unsigned)blocks), dim3(kRedThreads), 0, s, n, a0, stride, k, partials);
-  hipLaunchKernelGGL(k_mgs_factor, dim3(1), dim3(kMgsFactorThreads), 0, s, partials, (int)blocks, k, cf);
+  return (int)blocks;
+}
+void launch_mgs_factor(hipStream_t s, const double* partials, int nblocks, int k, double* cf) {
+  hipLaunchKernelGGL(k_mgs_factor, dim3(1), dim3(kMgsFactorThreads), 0, s, partials, nblocks, k, cf);
+}
+void launch_mgs_apply(hipStream_t s, long n, double* a0, long stride, int k, const double* cf) {
   const bool vec2 = (n & 1) == 0 && (stride & 1) == 0 && (((uintptr_t)a0) & 15) == 0;
   if (vec2) hipLaunchKernelGGL((k_mgs_apply<true>), dim3(blocks_for(n / 2)), dim3(256), 0, s, n, a0, stride, k, cf);
   else hipLaunchKernelGGL((k_mgs_apply<false>), dim3(blocks_for(n)), dim3(256), 0, s, n, a0, stride, k, cf);
+}
+// all three on the k columns a0, a0 + stride, ...; cf: mgs_block_words() doubles whose gate word the column-by-column
+// launches behind this take
+void launch_mgs_blocked(hipStream_t s, long n, double* a0, long stride, int k, double* partials, double* cf) {
+  const int blocks = launch_mgs_gram(s, n, a0, stride, k, partials);
+  launch_mgs_factor(s, partials, blocks, k, cf);
+  launch_mgs_apply(s, n, a0, stride, k, cf);
 }
 
 void launch_mgs_step(hipStream_t s, long n, const double* partials_in, double* u, long stride, int m, double* partials_out, int nb_in,

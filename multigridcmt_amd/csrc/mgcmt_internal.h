@@ -192,6 +192,11 @@ int mgs_block_max();
 int mgs_block_words();
 int mgs_block_gate_word();
 void launch_mgs_blocked(hipStream_t s, long n, double* a0, long stride, int k, double* partials, double* cf);
+// its three launches one by one (a sharded plan all-reduces the Gram matrix between the first two): per-block partial sums
+// (returns the number of blocks), the factor from `nblocks` partial sums per entry, Q = A R^-1
+int launch_mgs_gram(hipStream_t s, long n, const double* a0, long stride, int k, double* partials);
+void launch_mgs_factor(hipStream_t s, const double* partials, int nblocks, int k, double* cf);
+void launch_mgs_apply(hipStream_t s, long n, double* a0, long stride, int k, const double* cf);
 
 // banded LU of (A - mu I) on the coarsest level and its solves (one workgroup per vector)
 struct KBand {

@@ -149,6 +149,9 @@ bool runs_beside(hipStream_t main, hipStream_t cand, int* d_sink) {
 
 namespace mgcmt {
 
+// words of the reduction buffer: the 2 * kMaxVec of the sums the API takes (mgcmt_allreduce_sum), the 78 entries of a Gram matrix
+constexpr int kRedWords = 128;
+
 struct ShardComm {
   int rank = 0, nranks = 1;
   RcclComm nccl = nullptr;  // transport 1
@@ -166,7 +169,7 @@ struct ShardComm {
   bool lane_checked = false;  // comm_stream has been tried against the cycle's stream (pick_exchange_stream)
   hipStream_t lane_for = nullptr;
   int emulate_of = 0;     // > 1 on a ONE-rank communicator in self-ring mode: the plan is rank R's strip of an N-rank job (timing rehearsal)
-  double* d_red = nullptr;  // [2 * kMaxVec] reduction results (inner products of the sharded Gram-Schmidt, mgcmt_allreduce_sum)
+  double* d_red = nullptr;  // [kRedWords] reduction results (inner products of the sharded Gram-Schmidt, mgcmt_allreduce_sum)
   std::vector<double> h_red;
 };
 
@@ -397,7 +400,7 @@ int strip_pass(mgcmt_plan* p, int l, int kind, int n, double omega, int mode, in
   return run_msgs(p, msgs, s);
 }
 
-// sum over ranks of n <= 2 * kMaxVec doubles at c->d_red, in stream order (RCCL) or through the host (callbacks)
+// sum over ranks of n <= kRedWords doubles at c->d_red, in stream order (RCCL) or through the host (callbacks)
 int allreduce_device(mgcmt_plan* p, int n, hipStream_t s) {
   ShardComm* c = p->comm;
   if (c->nranks == 1 || n < 1) return MGCMT_OK;
@@ -407,7 +410,7 @@ int allreduce_device(mgcmt_plan* p, int n, hipStream_t s) {
     return MGCMT_OK;
   }
   if (!c->allreduce) return fail(MGCMT_ERR_INVALID, "communicator has no all-reduce transport");
-  c->h_red.resize(2 * kMaxVec);
+  c->h_red.resize(kRedWords);
   MG_HIP(hipMemcpyAsync(c->h_red.data(), c->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, s));
   MG_HIP(hipStreamSynchronize(s));
   if (c->allreduce(c->user, c->h_red.data(), n) != 0) return fail(MGCMT_ERR_HIP, "external all-reduce transport failed");
@@ -427,6 +430,26 @@ int sharded_gramschmidt(mgcmt_plan* p, int l, int k, hipStream_t s) {
   const long stride = p->levels[l].stride;
   double* a0 = p->kvec(l, MGCMT_SLOT_V, 0).p;
   double* pa = p->d_partials;
+  if (p->use_mgs_block && k >= 2 && k <= mgs_block_max() && p->d_mgs) {
+    // The two-pass form (kernels_blas.hip): this rank's rows of the Gram matrix, ONE all-reduce of its k (k + 1) / 2
+    // entries — every rank then factors the same matrix and takes the same decision —, Q = A R^-1 on this rank's
+    // rows.  The decision (the gate word) is read back: the column-by-column form below has collectives in it, which
+    // only the host can leave out.
+    const int npairs = k * (k + 1) / 2;
+    const int blocks = launch_mgs_gram(s, n, a0, stride, k, pa);
+    launch_final_sums(s, npairs, blocks, pa, c->d_red);
+    MG_TRY(post_launch());
+    MG_TRY(allreduce_device(p, npairs, s));
+    launch_mgs_factor(s, c->d_red, 1, k, p->d_mgs);
+    MG_TRY(post_launch());
+    double gate = 1.0;
+    MG_HIP(hipMemcpyAsync(&gate, p->d_mgs + mgs_block_gate_word(), sizeof(double), hipMemcpyDeviceToHost, s));
+    MG_HIP(hipStreamSynchronize(s));
+    if (gate == 0.0) {
+      launch_mgs_apply(s, n, a0, stride, k, p->d_mgs);
+      return post_launch();
+    }
+  }
   const int nb = reduce_blocks(n);
   launch_dot_partials(s, n, a0, a0, stride, k, pa);  // <a_0, a_t>, t = 0..k-1, this rank's rows
   launch_final_sums(s, k, nb, pa, c->d_red);
@@ -497,7 +520,7 @@ static int comm_common(mgcmt_plan* p, int rank, int nranks, ShardComm** out) {
   if (e == hipSuccess) e = hipEventCreate(&c->ev_boundary);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_edges);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_red, sizeof(double) * 2 * kMaxVec);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_red, sizeof(double) * kRedWords);
   if (e != hipSuccess) {
     comm_release(p);
     return fail(MGCMT_ERR_HIP, std::string("communicator resources: ") + hipGetErrorString(e));
