@@ -602,7 +602,9 @@ int gramschmidt_impl(mgcmt_plan* p, int l, int slot, int k, int modified, hipStr
     // which leaves a gate word up where its rounding errors (cond^2 eps) would show; the column-by-column launches
     // behind it return at once when the gate is down (MGCMT_OPT_MGS_BLOCK = 0: column by column only)
     const double* gate = nullptr;
-    if (p->use_mgs_block && k >= 2 && k <= mgs_block_max()) {
+    // (from 2^20 points on: below that the k + 1 gated launches behind the blocked form cost what it saves — measured at 10
+    // columns: 512^2 column by column ~70 us, blocked 53 + 50 us of gated launches; 1024^2 250 against 133 us)
+    if (p->use_mgs_block && k >= 2 && k <= mgs_block_max() && n >= p->mgs_block_min) {
       launch_mgs_blocked(s, n, a0, stride, k, p->d_partials, p->d_mgs);
       gate = p->d_mgs + mgs_block_gate_word();
     }
@@ -835,6 +837,8 @@ int mgcmt_plan_create(const mgcmt_plan_desc* d, mgcmt_plan** out) {
   p->has_mass = d->m_nterms > 0;
   p->h_shifts.assign(kMaxVec, 0.0);
   {
+    const char* mb = getenv("MGCMT_MGS_BLOCK_MIN");  // points per column from which Gram-Schmidt takes its two-pass form (tests, tuning)
+    if (mb && atol(mb) > 1) p->mgs_block_min = atol(mb);
     const char* e = getenv("MGCMT_TAIL_DENSE");  // "0": the tail as the LDS-resident launch by default (the host-only test build:
     p->use_tail_dense = !(e && e[0] == '0');     // emulating the 1024 workgroups that form the matrix takes minutes)
   }
@@ -1701,6 +1705,7 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
   }
   if (option == MGCMT_OPT_MGS_BLOCK) {
     p->use_mgs_block = value != 0;
+    p->mgs_block_min = value > 1 ? (long)value : (1L << 20);  // (a value > 1: the blocked form from that many points on — tests, tuning)
     p->graphs_invalidate();
     return MGCMT_OK;
   }

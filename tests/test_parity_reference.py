@@ -493,14 +493,16 @@ def test_rqmin_single_launch_equals_the_passes(trio, case, monkeypatch):
     assert rel_err(x1, x0_) < 1e-10
 
 
-def test_vcycle_matrix_on_levels_with_long_columns(trio):
+def test_vcycle_matrix_on_levels_with_long_columns(trio, monkeypatch):
     """vcycle_matrix (MGCMTSolver.py:375-436) at a size whose upper levels orthonormalise their columns by the two-pass
     form of the modified Gram-Schmidt (csrc/kernels_blas.hip: Gram matrix, Cholesky factor, Q = A R^-1 — columns of more
     than 4096 points) against the CPU restatement, which orthonormalises column by column as MGCMTProcessor.py:44-50
     does: three outer iterations of the drivers' shift-and-invert loop (2DPotMatrixVcycle.py:91-105), 128^2, six columns."""
     from oracle.sparse_ref import RefSolver
-    from multigridcmt_amd import _lib
+    from multigridcmt_amd.plan import release_plans
     solver, sm, _ = trio
+    monkeypatch.setenv("MGCMT_MGS_BLOCK_MIN", "4097")     # (the default threshold is 2^20 points: a size the restatement takes minutes for)
+    release_plans()                                        # the plan of this test is created under that setting
     g, k = 128, 6
     A = H(sm, g, "2d")
     modes = [(1, 1), (1, 2), (2, 1), (2, 2), (1, 3), (3, 1)]
@@ -515,3 +517,4 @@ def test_vcycle_matrix_on_levels_with_long_columns(trio):
         assert rel_err(w, wr) < NORTH_STAR, it
         assert np.abs(w.T @ w - np.eye(k)).max() < 1e-12
         V, Vr = w, wr
+    release_plans()
