@@ -339,8 +339,8 @@ typedef enum mgcmt_option {
                                0: one workgroup per vector everywhere */
   MGCMT_OPT_LEX_CHAIN = 6,  /* default 1: the nu Gauss-Seidel sweeps of a smoothing step run chained in ONE launch of the scan pipeline
                                (sweep s + 1 follows sweep s a few rows behind); 0: one launch per sweep.  Same arithmetic, same bits */
-  MGCMT_OPT_MGS_BLOCK = 7,  /* default 1: modified Gram-Schmidt of 2..12 columns of >= 2^20 points (a value > 1: of at least that many
-                               points) as two passes over the data (Gram matrix,
+  MGCMT_OPT_MGS_BLOCK = 7,  /* default 1: modified Gram-Schmidt of 2..12 columns too long for one workgroup (a value > 1: of at least
+                               that many points) as two passes over the data (Gram matrix,
                                its Cholesky factor R, Q = A R^-1 — what MGCMTProcessor.py:44-50 computes in exact arithmetic),
                                with the column-by-column kernels taking over on the device where the columns' condition
                                number would let the difference (cond^2 eps) show; 0: column by column always */

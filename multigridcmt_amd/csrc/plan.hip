@@ -602,8 +602,9 @@ int gramschmidt_impl(mgcmt_plan* p, int l, int slot, int k, int modified, hipStr
     // which leaves a gate word up where its rounding errors (cond^2 eps) would show; the column-by-column launches
     // behind it return at once when the gate is down (MGCMT_OPT_MGS_BLOCK = 0: column by column only)
     const double* gate = nullptr;
-    // (from 2^20 points on: below that the k + 1 gated launches behind the blocked form cost what it saves — measured at 10
-    // columns: 512^2 column by column ~70 us, blocked 53 + 50 us of gated launches; 1024^2 250 against 133 us)
+    // (on every level the one-workgroup kernel does not take — measured with the blocked form only from 2^20 points on: a
+    // 1024^2 cycle of 10 columns 1.32 ms against 1.10, a 4096^2 cycle 6.21 against 6.26: the gated launches cost less than
+    // the column steps of the middle levels)
     if (p->use_mgs_block && k >= 2 && k <= mgs_block_max() && n >= p->mgs_block_min) {
       launch_mgs_blocked(s, n, a0, stride, k, p->d_partials, p->d_mgs);
       gate = p->d_mgs + mgs_block_gate_word();
@@ -1705,7 +1706,7 @@ int mgcmt_plan_set_option(mgcmt_plan* p, int option, int value) {
   }
   if (option == MGCMT_OPT_MGS_BLOCK) {
     p->use_mgs_block = value != 0;
-    p->mgs_block_min = value > 1 ? (long)value : (1L << 20);  // (a value > 1: the blocked form from that many points on — tests, tuning)
+    p->mgs_block_min = value > 1 ? (long)value : 0;  // (a value > 1: the blocked form from that many points on — tuning)
     p->graphs_invalidate();
     return MGCMT_OK;
   }

@@ -72,7 +72,7 @@ struct mgcmt_plan {
   double* d_rqstate = nullptr;  // scalars of the device-resident Rayleigh-quotient minimisation (kernels_rq.hip)
   double* d_mgs = nullptr;  // the blocked Gram-Schmidt's R^-1 and gate word (kernels_blas.hip)
   bool use_mgs_block = true;
-  long mgs_block_min = 1L << 20;  // points per column from which a single plan takes the blocked form
+  long mgs_block_min = 0;  // points per column from which a single plan takes the blocked form (0: wherever the one-workgroup kernel does not apply)
   double* d_rqhistory = nullptr;  // Rayleigh quotients recorded by mgcmt_rq_line_step (MGCMT_RQ_HISTORY numbers)
   std::vector<double> h_shifts;
   bool has_mass = false;

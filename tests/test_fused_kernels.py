@@ -483,7 +483,7 @@ def test_blocked_gram_schmidt_of_long_columns(backend, k):
     results = {}
     for name, cols in (("well", A), ("ill", L)):
         for opt in (1, 0):
-            p.set_option(_lib.OPT_MGS_BLOCK, 4097 if opt else 0)          # (from 4097 points on: the default is 2^20)
+            p.set_option(_lib.OPT_MGS_BLOCK, opt)
             for q in range(k):
                 p.upload(0, _lib.SLOT_V, q, cols[:, q])
             p.gramschmidt(0, _lib.SLOT_V, k, modified=1)

@@ -501,8 +501,8 @@ def test_vcycle_matrix_on_levels_with_long_columns(trio, monkeypatch):
     from oracle.sparse_ref import RefSolver
     from multigridcmt_amd.plan import release_plans
     solver, sm, _ = trio
-    monkeypatch.setenv("MGCMT_MGS_BLOCK_MIN", "4097")     # (the default threshold is 2^20 points: a size the restatement takes minutes for)
-    release_plans()                                        # the plan of this test is created under that setting
+    monkeypatch.delenv("MGCMT_MGS_BLOCK_MIN", raising=False)   # (the tuning knob must not switch the form under test off)
+    release_plans()
     g, k = 128, 6
     A = H(sm, g, "2d")
     modes = [(1, 1), (1, 2), (2, 1), (2, 2), (1, 3), (3, 1)]
