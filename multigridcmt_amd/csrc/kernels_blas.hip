@@ -210,6 +210,8 @@ constexpr double kMgsBlockCond = 100.0;     // ||R||_F ||R^-1||_F of the unit-di
 constexpr int kMgsGateWord = kMgsBlockMax * kMgsBlockMax;  // out[kMgsGateWord]: 0 = done here, 1 = column by column
 constexpr int kMgsFactorThreads = 1024;
 
+// VEC2: 16-byte accesses, two points per trip (n even, 16-byte aligned columns)
+template <bool VEC2>
 __global__ void __launch_bounds__(kRedThreads) k_mgs_gram(long n, const double* __restrict__ a0, long stride, int k, double* __restrict__ partials) {
   constexpr int kWaves = kRedThreads / 64;
   __shared__ double s_part[kWaves][kMgsPairsMax];
@@ -217,15 +219,29 @@ __global__ void __launch_bounds__(kRedThreads) k_mgs_gram(long n, const double* 
   double acc[kMgsPairsMax];
 #pragma unroll
   for (int t = 0; t < kMgsPairsMax; ++t) acc[t] = 0.0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    double x[kMgsBlockMax];
+  const long count = VEC2 ? n / 2 : n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    if (VEC2) {
+      double2 x[kMgsBlockMax];
 #pragma unroll
-    for (int a = 0; a < kMgsBlockMax; ++a) x[a] = a < k ? a0[a * stride + i] : 0.0;
+      for (int a = 0; a < kMgsBlockMax; ++a) x[a] = a < k ? reinterpret_cast<const double2*>(a0 + a * stride)[i] : make_double2(0.0, 0.0);
 #pragma unroll
-    for (int a = 0; a < kMgsBlockMax; ++a) {
-      if (a < k) {  // (wave-uniform)
+      for (int a = 0; a < kMgsBlockMax; ++a) {
+        if (a < k) {  // (wave-uniform)
 #pragma unroll
-        for (int b = 0; b <= a; ++b) acc[a * (a + 1) / 2 + b] = fma(x[a], x[b], acc[a * (a + 1) / 2 + b]);
+          for (int b = 0; b <= a; ++b) acc[a * (a + 1) / 2 + b] = fma(x[a].y, x[b].y, fma(x[a].x, x[b].x, acc[a * (a + 1) / 2 + b]));
+        }
+      }
+    } else {
+      double x[kMgsBlockMax];
+#pragma unroll
+      for (int a = 0; a < kMgsBlockMax; ++a) x[a] = a < k ? a0[a * stride + i] : 0.0;
+#pragma unroll
+      for (int a = 0; a < kMgsBlockMax; ++a) {
+        if (a < k) {  // (wave-uniform)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) acc[a * (a + 1) / 2 + b] = fma(x[a], x[b], acc[a * (a + 1) / 2 + b]);
+        }
       }
     }
   }
@@ -794,9 +810,12 @@ int mgs_block_gate_word() { return kMgsGateWord; }
 // returns the number of blocks: partials[pair * blocks + block], at most 78 * 768 doubles); the factor from sums of
 // `nblocks` partials each (1: the sums themselves — all-reduced over the ranks of a sharded plan); Q = A R^-1
 int launch_mgs_gram(hipStream_t s, long n, const double* a0, long stride, int k, double* partials) {
-  long blocks = (n + kRedThreads - 1) / kRedThreads;
+  const bool vec2 = (n & 1) == 0 && (stride & 1) == 0 && (((uintptr_t)a0) & 15) == 0;
+  long blocks = ((vec2 ? n / 2 : n) + kRedThreads - 1) / kRedThreads;
   if (blocks > kMgsGramBlocks) blocks = kMgsGramBlocks;
-  hipLaunchKernelGGL(k_mgs_gram, dim3((unsigned)blocks), dim3(kRedThreads), 0, s, n, a0, stride, k, partials);
+  if (blocks < 1) blocks = 1;
+  if (vec2) hipLaunchKernelGGL((k_mgs_gram<true>), dim3((unsigned)blocks), dim3(kRedThreads), 0, s, n, a0, stride, k, partials);
+  else hipLaunchKernelGGL((k_mgs_gram<false>), dim3((unsigned)blocks), dim3(kRedThreads), 0, s, n, a0, stride, k, partials);
   return (int)blocks;
 }
 void launch_mgs_factor(hipStream_t s, const double* partials, int nblocks, int k, double* cf) {
